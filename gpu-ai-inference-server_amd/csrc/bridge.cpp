@@ -1,0 +1,624 @@
+// C ABI of libinference_engine.so (declared in include/inference_bridge.h, include/inference_engine_ext.h).
+//
+// Behavioural mirror of the reference bridge (inference_engine/src/inference_bridge.cpp) and of the
+// Model/ModelImpl plumbing it drives (inference_engine/src/model.cpp:503-613, 734-794, 1158-1328), written
+// fresh for the MI355X engine.  Deliberate differences from the reference, all listed in DESIGN.md:
+//   * thread-safe (registry mutex, per-model mutex, shared ownership so an unload cannot free a model under
+//     an in-flight ModelInfer; the reference has no locks at all)
+//   * graph input/output names come from the ONNX graph, not the hard-coded {"input"}/{"output"}
+//     (model_repository.cpp:143-144) that makes densenet_onnx unservable in the reference
+//   * ModelInfer never writes more dims than the caller's array holds and zero-fills the unused tail of an
+//     output buffer (the reference overflows / leaves it uninitialised, inference_bridge.cpp:794-812)
+//   * no CPU execution provider: without a HIP device Load fails loudly
+#include <atomic>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <filesystem>
+#include <fstream>
+#include <iostream>
+#include <memory>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/inference_bridge.h"
+#include "../../include/inference_engine_ext.h"
+#include "executor.h"
+#include "kernels.h"
+#include "onnx_reader.h"
+#include "plan.h"
+#include "repository.h"
+
+static_assert(sizeof(Shape) == 16, "Shape layout");
+static_assert(sizeof(TensorData) == 48 && offsetof(TensorData, data) == 32 && offsetof(TensorData, data_size) == 40, "TensorData layout");
+static_assert(sizeof(ModelConfig) == 64 && offsetof(ModelConfig, dynamic_batching) == 56, "ModelConfig layout");
+static_assert(sizeof(ModelMetadata) == 72 && offsetof(ModelMetadata, load_time_ns) == 64, "ModelMetadata layout");
+static_assert(sizeof(ModelStats) == 32, "ModelStats layout");
+static_assert(sizeof(CudaMemoryInfo) == 24, "CudaMemoryInfo layout");
+
+namespace {
+
+char* dup_cstr(const std::string& s) {
+    char* p = static_cast<char*>(std::malloc(s.size() + 1));
+    if (p) std::memcpy(p, s.c_str(), s.size() + 1);
+    return p;
+}
+void set_error(ErrorMessage* error, const std::string& msg) {
+    if (error) *error = dup_cstr(msg);
+}
+
+struct ModelObj {
+    std::string path;
+    ModelType type = MODEL_UNKNOWN;
+    DeviceType device = DEVICE_GPU;
+    int device_id = 0;
+    std::string name, version;
+    std::vector<std::string> input_names, output_names;   // config names until Load replaces them with the graph's
+
+    std::mutex mu;                 // serialises Load / Unload / Infer on this model
+    std::atomic<bool> loaded{false};
+    std::string last_error;
+    std::shared_ptr<const ie::OnnxModel> onnx;
+    ie::ModelInfo info;
+    std::unique_ptr<ie::DeviceModel> dev;
+    int64_t load_time_ns = 0;
+    std::atomic<int64_t> inference_count{0}, total_ns{0}, last_ns{0};
+    std::atomic<size_t> memory_usage_bytes{0};
+
+    bool Load();      // model.cpp:503-548 + 825-871
+    void Unload();    // model.cpp:618-648
+};
+
+bool ModelObj::Load() {
+    std::lock_guard<std::mutex> g(mu);
+    auto t0 = std::chrono::steady_clock::now();
+    std::error_code ec;
+    if (!std::filesystem::exists(path, ec)) {
+        last_error = "Model file not found: " + path;
+        return false;
+    }
+    bool ok = false;
+    switch (type) {
+        case MODEL_TENSORFLOW: last_error = "TensorFlow model loading not implemented"; break;
+        case MODEL_TENSORRT: last_error = "TensorRT model loading not implemented"; break;
+        case MODEL_PYTORCH: last_error = "PyTorch model loading not implemented"; break;
+        case MODEL_CUSTOM: last_error = "Custom model loading not implemented"; break;
+        case MODEL_ONNX: {
+            try {
+                const std::string file = path + "/model.onnx";
+                if (!std::filesystem::exists(file, ec)) {
+                    last_error = "ONNX model file not found: " + file;
+                    break;
+                }
+                if (device != DEVICE_GPU) {
+                    last_error = "DEVICE_CPU execution is not provided by the MI355X engine (a HIP device is required)";
+                    break;
+                }
+                auto parsed = std::make_shared<ie::OnnxModel>(ie::LoadOnnxFile(file));
+                ie::ModelInfo inf = ie::DescribeModel(*parsed);
+                auto dm = std::make_unique<ie::DeviceModel>(parsed, device_id);
+                // Plan once at load (symbolic dims -> 1): rejects unsupported graphs here, like Ort::Session's
+                // constructor does, and puts the packed weights into HBM.
+                std::vector<std::vector<int64_t>> shapes;
+                for (auto& vi : inf.inputs) {
+                    std::vector<int64_t> s = vi.dims;
+                    for (auto& d : s) if (d <= 0) d = 1;
+                    shapes.push_back(s);
+                }
+                dm->Prepare(shapes);
+                input_names.clear();
+                output_names.clear();
+                for (auto& vi : inf.inputs) input_names.push_back(vi.name);
+                for (auto& vi : inf.outputs) output_names.push_back(vi.name);
+                memory_usage_bytes = inf.memory_usage_bytes;   // reference's estimate formula, model.cpp:979-1035
+                onnx = parsed;
+                info = std::move(inf);
+                dev = std::move(dm);
+                ok = true;
+            } catch (const std::exception& e) {
+                last_error = std::string("ONNX model loading error: ") + e.what();
+            }
+            break;
+        }
+        default: last_error = "Unsupported model type"; return false;
+    }
+    load_time_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    loaded = ok;
+    return ok;
+}
+
+void ModelObj::Unload() {
+    std::lock_guard<std::mutex> g(mu);
+    dev.reset();
+    onnx.reset();
+    loaded = false;
+}
+
+}  // namespace
+
+struct Model_t {
+    std::shared_ptr<ModelObj> model;
+};
+
+struct InferenceManager_t {
+    std::string repo_path;
+    std::unique_ptr<ie::Repository> repo;
+    std::mutex mu;
+    std::unordered_map<std::string, std::shared_ptr<ModelObj>> models;   // keyed by name only (bridge:320)
+};
+
+extern "C" {
+
+// ---- device queries ---------------------------------------------------------------------------------
+bool IsCudaAvailable(void) { return ie::HipDeviceCount() > 0; }
+int GetDeviceCount(void) { return ie::HipDeviceCount(); }
+const char* GetDeviceInfo(int device_id) {
+    try { return dup_cstr(ie::HipDeviceInfo(device_id)); } catch (...) { return dup_cstr("Unknown device"); }
+}
+CudaMemoryInfo GetMemoryInfo(int device_id) {
+    CudaMemoryInfo m{0, 0, 0};
+    size_t total = 0, fr = 0;
+    if (ie::HipMemoryInfo(device_id, &total, &fr)) { m.total = total; m.free = fr; m.used = total - fr; }
+    return m;
+}
+
+// ---- manager ------------------------------------------------------------------------------------------
+InferenceManagerHandle InferenceInitialize(const char* model_repository_path) {
+    try {
+        auto* mgr = new InferenceManager_t();
+        mgr->repo_path = model_repository_path ? model_repository_path : "";
+        mgr->repo = std::make_unique<ie::Repository>(mgr->repo_path);
+        mgr->repo->Scan();
+        return mgr;
+    } catch (const std::exception& e) {
+        std::cerr << "Exception in InferenceInitialize: " << e.what() << std::endl;
+        return nullptr;
+    } catch (...) { return nullptr; }
+}
+
+void InferenceShutdown(InferenceManagerHandle handle) {
+    try { delete handle; } catch (...) {}
+}
+
+bool InferenceLoadModel(InferenceManagerHandle handle, const char* model_name, const char* version, ErrorMessage* error) {
+    if (!handle || !model_name) { set_error(error, "Invalid handle or model name"); return false; }
+    try {
+        const std::string name = model_name;
+        handle->repo->Scan();   // pick up models added after InferenceInitialize (InferenceListModels rescans too)
+        std::string ver = version ? version : handle->repo->LatestVersion(name);
+        std::string path = handle->repo->ModelPath(name, ver);
+        std::error_code ec;
+        if (path.empty() || !std::filesystem::exists(path, ec)) { set_error(error, "Model path not found: " + path); return false; }
+        std::shared_ptr<ModelObj> obj;
+        {
+            std::lock_guard<std::mutex> g(handle->mu);
+            if (handle->models.count(name)) { set_error(error, "Model already loaded"); return false; }
+            const std::string onnx_file = path + "/model.onnx";
+            if (!std::filesystem::exists(onnx_file, ec)) { set_error(error, "ONNX file not found at: " + onnx_file); return false; }
+            if (ie::Repository::DetectType(path) == ie::RepoModelType::Unknown) { set_error(error, "Unable to determine model type"); return false; }
+            obj = std::make_shared<ModelObj>();
+            obj->path = path;
+            obj->type = MODEL_ONNX;
+            obj->device = DEVICE_GPU;      // bridge:346-347: GPU, device 0
+            obj->device_id = 0;
+            if (const char* d = std::getenv("IE_DEVICE_ID")) obj->device_id = std::atoi(d);
+            obj->name = name;
+            obj->version = ver.empty() ? handle->repo->LatestVersion(name) : ver;
+            obj->input_names = {"input"};
+            obj->output_names = {"output"};
+            handle->models[name] = obj;    // reserve the name; concurrent loaders of the same name now fail fast
+        }
+        if (!obj->Load()) {
+            std::string msg;
+            { std::lock_guard<std::mutex> g(obj->mu); msg = obj->last_error; }
+            std::lock_guard<std::mutex> g(handle->mu);
+            handle->models.erase(name);
+            set_error(error, msg);
+            return false;
+        }
+        return true;
+    } catch (const std::exception& e) { set_error(error, e.what()); return false; }
+    catch (...) { set_error(error, "unknown error"); return false; }
+}
+
+bool InferenceUnloadModel(InferenceManagerHandle handle, const char* model_name, const char* /*version*/, ErrorMessage* error) {
+    if (!handle || !model_name) { set_error(error, "Invalid handle or model name"); return false; }
+    try {
+        std::shared_ptr<ModelObj> obj;
+        {
+            std::lock_guard<std::mutex> g(handle->mu);
+            auto it = handle->models.find(model_name);
+            if (it == handle->models.end()) { set_error(error, "Model not found"); return false; }
+            obj = it->second;
+            handle->models.erase(it);
+        }
+        obj->Unload();   // waits for an in-flight ModelInfer; wrappers that still exist see "Model not loaded"
+        return true;
+    } catch (const std::exception& e) { set_error(error, e.what()); return false; }
+    catch (...) { set_error(error, "unknown error"); return false; }
+}
+
+bool InferenceIsModelLoaded(InferenceManagerHandle handle, const char* model_name, const char* /*version*/) {
+    if (!handle || !model_name) return false;
+    try {
+        std::lock_guard<std::mutex> g(handle->mu);
+        auto it = handle->models.find(model_name);
+        return it != handle->models.end() && it->second->loaded.load();
+    } catch (...) { return false; }
+}
+
+char** InferenceListModels(InferenceManagerHandle handle, int* num_models) {
+    if (!handle || !num_models) return nullptr;
+    try {
+        handle->repo->Scan();
+        std::vector<std::string> names = handle->repo->Models();
+        *num_models = int(names.size());
+        if (names.empty()) return nullptr;
+        char** out = static_cast<char**>(std::malloc(sizeof(char*) * names.size()));
+        for (size_t i = 0; i < names.size(); ++i) out[i] = dup_cstr(names[i]);
+        return out;
+    } catch (...) { *num_models = 0; return nullptr; }
+}
+
+void InferenceFreeModelList(char** models, int num_models) {
+    if (!models) return;
+    for (int i = 0; i < num_models; ++i) std::free(models[i]);
+    std::free(models);
+}
+
+// ---- model ----------------------------------------------------------------------------------------------
+ModelHandle ModelCreate(const char* model_path, ModelType type, const ModelConfig* config, DeviceType device, int device_id,
+                        ErrorMessage* error) {
+    if (!model_path || !config) { set_error(error, "Invalid model path or configuration"); return nullptr; }
+    try {
+        auto obj = std::make_shared<ModelObj>();
+        obj->path = model_path;
+        obj->type = type;
+        obj->device = device;
+        obj->device_id = device_id;
+        obj->name = config->name ? config->name : "";
+        obj->version = config->version ? config->version : "1";
+        for (int i = 0; i < config->num_inputs; ++i)
+            if (config->input_names && config->input_names[i]) obj->input_names.push_back(config->input_names[i]);
+        for (int i = 0; i < config->num_outputs; ++i)
+            if (config->output_names && config->output_names[i]) obj->output_names.push_back(config->output_names[i]);
+        return new Model_t{obj};
+    } catch (const std::exception& e) { set_error(error, e.what()); return nullptr; }
+    catch (...) { set_error(error, "unknown error"); return nullptr; }
+}
+
+void ModelDestroy(ModelHandle handle) {
+    try { delete handle; } catch (...) {}
+}
+
+bool ModelLoad(ModelHandle handle, ErrorMessage* error) {
+    if (!handle) { set_error(error, "Invalid model handle"); return false; }
+    try {
+        bool ok = handle->model->Load();
+        if (!ok) { std::lock_guard<std::mutex> g(handle->model->mu); set_error(error, handle->model->last_error); }
+        return ok;
+    } catch (const std::exception& e) { set_error(error, e.what()); return false; }
+    catch (...) { set_error(error, "unknown error"); return false; }
+}
+
+bool ModelUnload(ModelHandle handle, ErrorMessage* error) {
+    if (!handle) { set_error(error, "Invalid model handle"); return false; }
+    try { handle->model->Unload(); return true; }
+    catch (const std::exception& e) { set_error(error, e.what()); return false; }
+    catch (...) { set_error(error, "unknown error"); return false; }
+}
+
+bool ModelIsLoaded(ModelHandle handle) {
+    if (!handle) return false;
+    try { return handle->model->loaded.load(); } catch (...) { return false; }
+}
+
+bool ModelInfer(ModelHandle handle, const TensorData* inputs, int num_inputs, TensorData* outputs, int num_outputs,
+                ErrorMessage* error) {
+    if (!handle) { set_error(error, "Invalid model handle"); return false; }
+    ModelObj& M = *handle->model;
+    if (!M.loaded.load()) { set_error(error, "Model not loaded"); return false; }
+    if (!inputs || num_inputs <= 0 || !outputs || num_outputs <= 0) { set_error(error, "Invalid parameters"); return false; }
+    try {
+        std::lock_guard<std::mutex> g(M.mu);
+        if (!M.loaded.load() || !M.dev) { set_error(error, "Model not loaded"); return false; }
+        auto failv = [&](const std::string& msg) { M.last_error = msg; set_error(error, msg); return false; };
+
+        // ---- ValidateInputs (model.cpp:734-794): count, then names ----
+        const auto& gin = M.info.inputs;
+        if (size_t(num_inputs) != gin.size())
+            return failv("Expected " + std::to_string(gin.size()) + " inputs, got " + std::to_string(num_inputs));
+        for (int i = 0; i < num_inputs; ++i) {
+            const std::string nm = inputs[i].name ? inputs[i].name : "";
+            bool known = false;
+            for (auto& vi : gin) if (vi.name == nm) known = true;
+            if (!known) return failv("Unexpected input name: " + nm);
+        }
+        // From here on the reference counts the call in its statistics even when it fails (model.cpp:572-612).
+        const auto t0 = std::chrono::steady_clock::now();
+        bool ok = false;
+        std::string err;
+        do {
+            // ---- InferONNX (model.cpp:1158-1328): order inputs by graph index ----
+            std::vector<const void*> in_ptr(gin.size(), nullptr);
+            std::vector<size_t> in_bytes(gin.size(), 0);
+            std::vector<std::vector<int64_t>> shapes(gin.size());
+            std::vector<char> provided(gin.size(), 0);
+            bool bad = false;
+            for (int i = 0; i < num_inputs && !bad; ++i) {
+                const TensorData& t = inputs[i];
+                const std::string nm = t.name ? t.name : "";
+                for (size_t k = 0; k < gin.size(); ++k) {
+                    if (gin[k].name != nm) continue;
+                    if (t.data_type != DATATYPE_FLOAT32) { err = "Unsupported data type for input: " + nm; bad = true; break; }
+                    provided[k] = 1;
+                    shapes[k].clear();
+                    if (t.shape.dims && t.shape.num_dims > 0) shapes[k].assign(t.shape.dims, t.shape.dims + t.shape.num_dims);
+                    in_ptr[k] = (t.data && t.data_size > 0) ? t.data : nullptr;
+                    in_bytes[k] = in_ptr[k] ? t.data_size : 0;
+                }
+            }
+            if (bad) break;
+            for (size_t k = 0; k < gin.size(); ++k)
+                if (!provided[k]) { err = "Required input tensor not provided: " + gin[k].name; bad = true; break; }
+            if (bad) break;
+            try {
+                ie::PlanInstance& pi = M.dev->Prepare(shapes);
+                std::vector<void*> out_ptr;
+                std::vector<size_t> out_bytes;
+                for (int i = 0; i < num_outputs; ++i) {
+                    const bool copy = outputs[i].data_type == DATATYPE_FLOAT32 && outputs[i].data && outputs[i].data_size > 0;
+                    out_ptr.push_back(copy ? outputs[i].data : nullptr);
+                    out_bytes.push_back(copy ? outputs[i].data_size : 0);
+                }
+                M.dev->InferHost(pi, in_ptr, in_bytes, out_ptr, out_bytes);
+                // outputs by index, in graph-output order (bridge:787-813)
+                for (int i = 0; i < num_outputs && size_t(i) < pi.plan.outputs.size(); ++i) {
+                    const auto& dims = pi.plan.outputs[size_t(i)].dims;
+                    const int cap = outputs[i].shape.dims ? outputs[i].shape.num_dims : 0;
+                    const int nd = int(dims.size());
+                    if (outputs[i].shape.dims) {
+                        const int nw = nd < cap ? nd : cap;     // never write past the caller's array
+                        for (int j = 0; j < nw; ++j) outputs[i].shape.dims[j] = dims[size_t(j)];
+                        outputs[i].shape.num_dims = nw;
+                    }
+                }
+                ok = true;
+            } catch (const std::exception& e) {
+                err = std::string("ONNX inference error: ") + e.what();
+            }
+        } while (false);
+        const int64_t ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        M.inference_count.fetch_add(1);
+        M.total_ns.fetch_add(ns);
+        M.last_ns.store(ns);
+        if (!ok) return failv(err);
+        return true;
+    } catch (const std::exception& e) { set_error(error, e.what()); return false; }
+    catch (...) { set_error(error, "unknown error"); return false; }
+}
+
+ModelMetadata* ModelGetMetadata(ModelHandle handle) {
+    if (!handle) return nullptr;
+    try {
+        ModelObj& M = *handle->model;
+        std::lock_guard<std::mutex> g(M.mu);
+        auto* md = static_cast<ModelMetadata*>(std::calloc(1, sizeof(ModelMetadata)));
+        md->name = dup_cstr(M.name);
+        md->version = dup_cstr(M.version);
+        md->model_type = M.type;
+        md->description = dup_cstr("");
+        md->load_time_ns = M.load_time_ns;
+        auto fill = [](const std::vector<std::string>& v, const char*** arr, int* n) {
+            *n = int(v.size());
+            *arr = nullptr;
+            if (v.empty()) return;
+            *arr = static_cast<const char**>(std::malloc(sizeof(char*) * v.size()));
+            for (size_t i = 0; i < v.size(); ++i) (*arr)[i] = dup_cstr(v[i]);
+        };
+        fill(M.input_names, &md->inputs, &md->num_inputs);
+        fill(M.output_names, &md->outputs, &md->num_outputs);
+        return md;
+    } catch (...) { return nullptr; }
+}
+
+void ModelFreeMetadata(ModelMetadata* md) {
+    if (!md) return;
+    std::free(const_cast<char*>(md->name));
+    std::free(const_cast<char*>(md->version));
+    std::free(const_cast<char*>(md->description));
+    if (md->inputs) { for (int i = 0; i < md->num_inputs; ++i) std::free(const_cast<char*>(md->inputs[i])); std::free(md->inputs); }
+    if (md->outputs) { for (int i = 0; i < md->num_outputs; ++i) std::free(const_cast<char*>(md->outputs[i])); std::free(md->outputs); }
+    std::free(md);
+}
+
+ModelStats* ModelGetStats(ModelHandle handle) {
+    if (!handle) return nullptr;
+    try {
+        ModelObj& M = *handle->model;
+        auto* s = static_cast<ModelStats*>(std::calloc(1, sizeof(ModelStats)));
+        s->inference_count = M.inference_count.load();
+        s->total_inference_time_ns = M.total_ns.load();
+        s->last_inference_time_ns = M.last_ns.load();
+        s->memory_usage_bytes = M.memory_usage_bytes.load();
+        return s;
+    } catch (...) { return nullptr; }
+}
+
+void ModelFreeStats(ModelStats* stats) { std::free(stats); }
+
+void FreeErrorMessage(ErrorMessage error) { std::free(error); }
+
+ModelHandle GetModelHandle(InferenceManagerHandle handle, const char* model_name, const char* /*version*/, ErrorMessage* error) {
+    if (!handle || !model_name) { set_error(error, "Invalid handle or model name"); return nullptr; }
+    try {
+        std::lock_guard<std::mutex> g(handle->mu);
+        auto it = handle->models.find(model_name);
+        if (it == handle->models.end()) { set_error(error, "Model not found in loaded models"); return nullptr; }
+        return new Model_t{it->second};   // wrapper shares ownership; ModelDestroy frees only the wrapper
+    } catch (const std::exception& e) { set_error(error, e.what()); return nullptr; }
+    catch (...) { set_error(error, "unknown error"); return nullptr; }
+}
+
+// ---- extensions (include/inference_engine_ext.h) --------------------------------------------------------------
+static void json_vi(std::ostringstream& o, const std::vector<ie::OnnxValueInfo>& v) {
+    o << "[";
+    for (size_t i = 0; i < v.size(); ++i) {
+        o << (i ? "," : "") << "{\"name\":\"" << v[i].name << "\",\"elem_type\":" << v[i].elem_type << ",\"dims\":[";
+        for (size_t k = 0; k < v[i].dims.size(); ++k) o << (k ? "," : "") << v[i].dims[k];
+        o << "]}";
+    }
+    o << "]";
+}
+
+char* EngineDescribeModel(const char* path, int batch, ErrorMessage* error) {
+    if (!path) { set_error(error, "Invalid parameters"); return nullptr; }
+    try {
+        std::string file = path;
+        std::error_code ec;
+        if (std::filesystem::is_directory(file, ec)) file += "/model.onnx";
+        if (!std::filesystem::exists(file, ec)) { set_error(error, "ONNX model file not found: " + file); return nullptr; }
+        ie::OnnxModel m = ie::LoadOnnxFile(file);
+        ie::ModelInfo info = ie::DescribeModel(m);
+        std::ostringstream o;
+        o << "{\"ir_version\":" << m.ir_version << ",\"opset\":" << m.opset << ",\"producer\":\"" << m.producer
+          << "\",\"num_nodes\":" << m.nodes.size() << ",\"num_initializers\":" << m.initializers.size()
+          << ",\"memory_usage_bytes\":" << info.memory_usage_bytes << ",\"inputs\":";
+        json_vi(o, info.inputs);
+        o << ",\"outputs\":";
+        json_vi(o, info.outputs);
+        if (batch > 0) {
+            std::vector<std::vector<int64_t>> shapes;
+            for (auto& vi : info.inputs) {
+                std::vector<int64_t> s = vi.dims;
+                for (size_t k = 0; k < s.size(); ++k) if (s[k] <= 0) s[k] = (k == 0 ? batch : 1);
+                shapes.push_back(s);
+            }
+            o << ",\"plan\":" << ie::PlanToJson(ie::BuildPlan(m, shapes));
+        }
+        o << "}";
+        return dup_cstr(o.str());
+    } catch (const std::exception& e) { set_error(error, e.what()); return nullptr; }
+    catch (...) { set_error(error, "unknown error"); return nullptr; }
+}
+
+bool EnginePrepare(ModelHandle handle, const Shape* input_shapes, int num_inputs, void** d_inputs, void** d_outputs,
+                   int num_outputs, ErrorMessage* error) {
+    if (!handle) { set_error(error, "Invalid model handle"); return false; }
+    try {
+        ModelObj& M = *handle->model;
+        std::lock_guard<std::mutex> g(M.mu);
+        if (!M.loaded.load() || !M.dev) { set_error(error, "Model not loaded"); return false; }
+        if (!input_shapes || num_inputs <= 0) { set_error(error, "Invalid parameters"); return false; }
+        std::vector<std::vector<int64_t>> shapes;
+        for (int i = 0; i < num_inputs; ++i) {
+            if (!input_shapes[i].dims || input_shapes[i].num_dims <= 0) { set_error(error, "Invalid parameters"); return false; }
+            shapes.emplace_back(input_shapes[i].dims, input_shapes[i].dims + input_shapes[i].num_dims);
+        }
+        ie::PlanInstance& pi = M.dev->Prepare(shapes);
+        for (int i = 0; d_inputs && i < num_inputs && size_t(i) < pi.plan.inputs.size(); ++i)
+            d_inputs[i] = pi.buffers[size_t(pi.plan.inputs[size_t(i)].view.buf)];
+        for (int i = 0; d_outputs && i < num_outputs && size_t(i) < pi.plan.outputs.size(); ++i)
+            d_outputs[i] = pi.buffers[size_t(pi.plan.outputs[size_t(i)].view.buf)];
+        return true;
+    } catch (const std::exception& e) { set_error(error, e.what()); return false; }
+    catch (...) { set_error(error, "unknown error"); return false; }
+}
+
+bool EngineRunPrepared(ModelHandle handle, int iters, int sync, ErrorMessage* error) {
+    if (!handle) { set_error(error, "Invalid model handle"); return false; }
+    try {
+        ModelObj& M = *handle->model;
+        std::lock_guard<std::mutex> g(M.mu);
+        if (!M.loaded.load() || !M.dev || !M.dev->current()) { set_error(error, "Model not prepared"); return false; }
+        for (int i = 0; i < iters; ++i) M.dev->Enqueue(*M.dev->current());
+        if (sync) M.dev->Synchronize();
+        return true;
+    } catch (const std::exception& e) { set_error(error, e.what()); return false; }
+    catch (...) { set_error(error, "unknown error"); return false; }
+}
+
+bool EngineSynchronize(ModelHandle handle, ErrorMessage* error) {
+    if (!handle) { set_error(error, "Invalid model handle"); return false; }
+    try {
+        ModelObj& M = *handle->model;
+        std::lock_guard<std::mutex> g(M.mu);
+        if (!M.dev) { set_error(error, "Model not loaded"); return false; }
+        M.dev->Synchronize();
+        return true;
+    } catch (const std::exception& e) { set_error(error, e.what()); return false; }
+    catch (...) { set_error(error, "unknown error"); return false; }
+}
+
+void* EngineGetStream(ModelHandle handle) {
+    if (!handle) return nullptr;
+    try {
+        ModelObj& M = *handle->model;
+        std::lock_guard<std::mutex> g(M.mu);
+        return M.dev ? static_cast<void*>(M.dev->stream()) : nullptr;
+    } catch (...) { return nullptr; }
+}
+
+char* EngineProfile(ModelHandle handle, int iters, ErrorMessage* error) {
+    if (!handle) { set_error(error, "Invalid model handle"); return nullptr; }
+    try {
+        ModelObj& M = *handle->model;
+        std::lock_guard<std::mutex> g(M.mu);
+        if (!M.loaded.load() || !M.dev || !M.dev->current()) { set_error(error, "Model not prepared"); return nullptr; }
+        auto t = M.dev->Profile(*M.dev->current(), iters > 0 ? iters : 1);
+        std::ostringstream o;
+        o.precision(9);
+        o << "[";
+        for (size_t i = 0; i < t.size(); ++i) {
+            std::string nm;
+            for (char c : t[i].name) if (c != '"' && c != '\\') nm += c;
+            o << (i ? "," : "") << "{\"name\":\"" << nm << "\",\"kernel\":\"" << t[i].kernel << "\",\"ms\":" << t[i].ms
+              << ",\"flops\":" << t[i].flops << ",\"bytes\":" << t[i].bytes << "}";
+        }
+        o << "]";
+        return dup_cstr(o.str());
+    } catch (const std::exception& e) { set_error(error, e.what()); return nullptr; }
+    catch (...) { set_error(error, "unknown error"); return nullptr; }
+}
+
+bool EngineGetWeightBlob(ModelHandle handle, void** d_ptr, size_t* bytes, ErrorMessage* error) {
+    if (!handle || !d_ptr || !bytes) { set_error(error, "Invalid parameters"); return false; }
+    try {
+        ModelObj& M = *handle->model;
+        std::lock_guard<std::mutex> g(M.mu);
+        if (!M.loaded.load() || !M.dev) { set_error(error, "Model not loaded"); return false; }
+        *d_ptr = M.dev->weights();
+        *bytes = M.dev->weight_bytes();
+        return true;
+    } catch (const std::exception& e) { set_error(error, e.what()); return false; }
+    catch (...) { set_error(error, "unknown error"); return false; }
+}
+
+bool EngineVectorAdd(const float* a, const float* b, float* result, size_t n, ErrorMessage* error) {
+    if (!a || !b || !result) { set_error(error, "Invalid parameters"); return false; }
+    if (ie::HipDeviceCount() <= 0) { set_error(error, "No HIP device available"); return false; }
+    float *da = nullptr, *db = nullptr, *dr = nullptr;
+    bool ok = false;
+    std::string msg;
+    auto chk = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess) { msg = std::string("HIP error in ") + what + ": " + hipGetErrorString(e); return false; }
+        return true;
+    };
+    const size_t bytes = n * sizeof(float);
+    if (n == 0) return true;
+    if (chk(hipMalloc(reinterpret_cast<void**>(&da), bytes), "hipMalloc") && chk(hipMalloc(reinterpret_cast<void**>(&db), bytes), "hipMalloc") &&
+        chk(hipMalloc(reinterpret_cast<void**>(&dr), bytes), "hipMalloc") && chk(hipMemcpy(da, a, bytes, hipMemcpyHostToDevice), "hipMemcpy") &&
+        chk(hipMemcpy(db, b, bytes, hipMemcpyHostToDevice), "hipMemcpy") && chk(ie::LaunchVectorAdd(da, db, dr, int64_t(n), nullptr), "vector_add") &&
+        chk(hipDeviceSynchronize(), "hipDeviceSynchronize") && chk(hipMemcpy(result, dr, bytes, hipMemcpyDeviceToHost), "hipMemcpy"))
+        ok = true;
+    if (da) (void)hipFree(da);
+    if (db) (void)hipFree(db);
+    if (dr) (void)hipFree(dr);
+    if (!ok) set_error(error, msg);
+    return ok;
+}
+
+}  // extern "C"

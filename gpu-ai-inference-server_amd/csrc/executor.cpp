@@ -1,0 +1,309 @@
+#include "executor.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+
+#include "igemm_tiles.h"
+#include "kernels.h"
+
+namespace ie {
+namespace {
+
+void check(hipError_t e, const char* what) {
+    if (e != hipSuccess) throw std::runtime_error(std::string("HIP error in ") + what + ": " + hipGetErrorString(e));
+}
+
+TensorArg make_arg(const PlanInstance& pi, const View& v) {
+    TensorArg t;
+    float* base = pi.buffers.at(size_t(v.buf));
+    t.n = int(v.n); t.h = int(v.h); t.w = int(v.w); t.c = int(v.c);
+    if (v.nchw) {
+        t.p = base;
+        t.sw = 1; t.sh = v.w; t.sc = v.h * v.w; t.sn = v.c * v.h * v.w;
+    } else {
+        t.p = base + v.c_off;
+        t.sc = 1; t.sw = v.pitch; t.sh = v.w * v.pitch; t.sn = v.h * v.w * v.pitch;
+    }
+    return t;
+}
+
+constexpr size_t kChunk = size_t(4) << 20;   // pinned staging chunk
+constexpr int kSlots = 4;
+
+std::once_flag g_kernels_once;
+hipError_t g_kernels_err = hipSuccess;
+
+}  // namespace
+
+int HipDeviceCount() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+std::string HipDeviceInfo(int device_id) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device_id) != hipSuccess) { (void)hipGetLastError(); return "Unknown device"; }
+    // Same shape as the reference's string (cuda_utils.cu:51-54); on AMD the "compute capability" pair is the
+    // gfx major.minor HIP reports (9.5 for gfx950).
+    return "Device " + std::to_string(device_id) + ": " + p.name + " (Compute Capability " + std::to_string(p.major) + "." +
+           std::to_string(p.minor) + ")";
+}
+
+bool HipMemoryInfo(int device_id, size_t* total, size_t* free_b) {
+    int prev = 0;
+    if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (hipSetDevice(device_id) != hipSuccess) { (void)hipGetLastError(); return false; }
+    bool ok = hipMemGetInfo(free_b, total) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    (void)hipSetDevice(prev);
+    return ok;
+}
+
+DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id) : model_(std::move(model)), device_(device_id) {
+    int n = HipDeviceCount();
+    if (n <= 0) throw std::runtime_error("No HIP device available: the MI355X engine has no CPU fallback");
+    if (device_id < 0 || device_id >= n) throw std::runtime_error("Invalid device id " + std::to_string(device_id));
+    check(hipSetDevice(device_), "hipSetDevice");
+    std::call_once(g_kernels_once, [] { g_kernels_err = InitKernels(); });
+    check(g_kernels_err, "InitKernels");
+    check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
+    const char* ng = std::getenv("IE_DISABLE_GRAPH");
+    use_graph_ = !(ng && ng[0] == '1');
+    pinned_bytes_ = kChunk * kSlots;
+    check(hipHostMalloc(&pinned_, pinned_bytes_, hipHostMallocDefault), "hipHostMalloc");
+}
+
+DeviceModel::~DeviceModel() {
+    (void)hipSetDevice(device_);
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    for (auto& kv : plans_) {
+        if (kv.second->graph_exec) (void)hipGraphExecDestroy(kv.second->graph_exec);
+        for (float* b : kv.second->buffers) if (b) (void)hipFree(b);
+    }
+    if (d_weights_) (void)hipFree(d_weights_);
+    if (pinned_) (void)hipHostFree(pinned_);
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+PlanInstance& DeviceModel::Prepare(const std::vector<std::vector<int64_t>>& shapes) {
+    std::vector<int64_t> key;
+    for (auto& s : shapes) { key.push_back(int64_t(s.size())); key.insert(key.end(), s.begin(), s.end()); }
+    auto it = plans_.find(key);
+    if (it != plans_.end()) { current_ = it->second.get(); return *current_; }
+
+    check(hipSetDevice(device_), "hipSetDevice");
+    auto pi = std::make_unique<PlanInstance>();
+    pi->plan = BuildPlan(*model_, shapes);
+    if (!d_weights_) {
+        weight_floats_ = pi->plan.weights.size();
+        check(hipMalloc(reinterpret_cast<void**>(&d_weights_), std::max<size_t>(weight_floats_, 4) * sizeof(float)), "hipMalloc(weights)");
+        device_bytes_ += weight_floats_ * sizeof(float);
+        check(hipMemcpy(d_weights_, pi->plan.weights.data(), weight_floats_ * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy(weights)");
+    } else if (pi->plan.weights.size() != weight_floats_) {
+        throw std::runtime_error("internal error: weight blob layout depends on the input shape");
+    }
+    // the host copy of the blob is only needed for the first upload
+    std::vector<float>().swap(pi->plan.weights);
+    for (int64_t nfl : pi->plan.buffer_floats) {
+        float* p = nullptr;
+        size_t bytes = size_t(std::max<int64_t>(nfl, 4)) * sizeof(float);
+        check(hipMalloc(reinterpret_cast<void**>(&p), bytes), "hipMalloc(activations)");
+        check(hipMemsetAsync(p, 0, bytes, stream_), "hipMemset(activations)");
+        device_bytes_ += bytes;
+        pi->buffers.push_back(p);
+    }
+    check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+
+    if (use_graph_) {
+        hipGraph_t graph = nullptr;
+        check(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+        try {
+            RunSteps(*pi, nullptr, nullptr);
+        } catch (...) {
+            (void)hipStreamEndCapture(stream_, &graph);
+            if (graph) (void)hipGraphDestroy(graph);
+            throw;
+        }
+        check(hipStreamEndCapture(stream_, &graph), "hipStreamEndCapture");
+        hipError_t e = hipGraphInstantiate(&pi->graph_exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        check(e, "hipGraphInstantiate");
+        pi->graph_ready = true;
+    }
+    current_ = pi.get();
+    plans_[key] = std::move(pi);
+    return *current_;
+}
+
+void DeviceModel::LaunchStep(const PlanInstance& pi, const Step& s) {
+    const float* wb = d_weights_;
+    auto wp = [&](int64_t off) -> const float* { return off >= 0 ? wb + off : nullptr; };
+    switch (s.kind) {
+        case StepKind::Conv: {
+            ConvArgs a;
+            a.in = make_arg(pi, s.in);
+            a.out = make_arg(pi, s.out);
+            a.w = wp(s.w_off);
+            a.bias = wp(s.bias_off);
+            a.pre_scale = wp(s.pre_scale_off);
+            a.pre_shift = wp(s.pre_shift_off);
+            a.kh = s.kh; a.kw = s.kw; a.sh = s.sh; a.sw = s.sw; a.pt = s.pt; a.pl = s.pl;
+            a.pre_relu = s.pre_relu; a.relu = s.relu;
+            if (s.algo == ConvAlgo::Naive) check(LaunchConvNaive(a, stream_), "conv_naive");
+            else check(LaunchConvIgemm(a, s.tile, s.algo == ConvAlgo::IgemmVec ? 1 : 0, stream_), "conv_igemm");
+            break;
+        }
+        case StepKind::Pool: {
+            PoolArgs a;
+            a.in = make_arg(pi, s.in);
+            a.out = make_arg(pi, s.out);
+            a.kh = s.kh; a.kw = s.kw; a.sh = s.sh; a.sw = s.sw; a.pt = s.pt; a.pl = s.pl; a.pb = s.pb; a.pr = s.pr;
+            a.is_max = s.pool_max; a.count_include_pad = s.count_include_pad;
+            check(LaunchPool(a, stream_), "pool");
+            break;
+        }
+        case StepKind::GlobalAvgPool:
+            check(LaunchGlobalAvgPool(make_arg(pi, s.in), make_arg(pi, s.out), wp(s.pre_scale_off), wp(s.pre_shift_off),
+                                      s.pre_relu, stream_), "global_avg_pool");
+            break;
+        case StepKind::Eltwise: {
+            EltArgs a;
+            a.a = make_arg(pi, s.in);
+            if (s.has_in2) a.b = make_arg(pi, s.in2);
+            a.out = make_arg(pi, s.out);
+            a.scale = wp(s.pre_scale_off);
+            a.shift = wp(s.pre_shift_off);
+            a.relu = s.relu;
+            check(LaunchEltwise(a, stream_), "eltwise");
+            break;
+        }
+        case StepKind::Copy:
+            check(LaunchCopy(make_arg(pi, s.in), make_arg(pi, s.out), stream_), "copy");
+            break;
+    }
+}
+
+static std::string kernel_label(const Step& s) {
+    switch (s.kind) {
+        case StepKind::Conv:
+            if (s.algo == ConvAlgo::Naive) return "conv_naive_kernel";
+            return std::string("conv_igemm_kernel<") + std::to_string(kIgemmTiles[s.tile].bm) + "x" +
+                   std::to_string(kIgemmTiles[s.tile].bn) + (s.algo == ConvAlgo::IgemmVec ? ",vec>" : ",scalar>");
+        case StepKind::Pool: return "pool_kernel";
+        case StepKind::GlobalAvgPool: return "gap_kernel";
+        case StepKind::Eltwise: return "eltwise_kernel";
+        case StepKind::Copy: return "copy_kernel";
+    }
+    return "?";
+}
+
+void DeviceModel::RunSteps(PlanInstance& pi, std::vector<StepTiming>* timings, std::vector<hipEvent_t>* events) {
+    size_t k = 0;
+    if (events) check(hipEventRecord((*events)[k++], stream_), "hipEventRecord");
+    for (const Step& s : pi.plan.steps) {
+        LaunchStep(pi, s);
+        if (events) check(hipEventRecord((*events)[k++], stream_), "hipEventRecord");
+    }
+    (void)timings;
+}
+
+void DeviceModel::Enqueue(PlanInstance& pi) {
+    check(hipSetDevice(device_), "hipSetDevice");
+    if (pi.graph_ready) check(hipGraphLaunch(pi.graph_exec, stream_), "hipGraphLaunch");
+    else RunSteps(pi, nullptr, nullptr);
+}
+
+void DeviceModel::Synchronize() {
+    check(hipSetDevice(device_), "hipSetDevice");
+    check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+}
+
+std::vector<StepTiming> DeviceModel::Profile(PlanInstance& pi, int iters) {
+    check(hipSetDevice(device_), "hipSetDevice");
+    const size_t ns = pi.plan.steps.size();
+    std::vector<hipEvent_t> ev(ns + 1);
+    for (auto& e : ev) check(hipEventCreate(&e), "hipEventCreate");
+    std::vector<StepTiming> out(ns);
+    for (size_t i = 0; i < ns; ++i) {
+        out[i].name = pi.plan.steps[i].name;
+        out[i].kernel = kernel_label(pi.plan.steps[i]);
+        out[i].flops = pi.plan.steps[i].flops;
+        out[i].bytes = pi.plan.steps[i].bytes;
+    }
+    try {
+        RunSteps(pi, nullptr, nullptr);   // warm
+        check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+        for (int it = 0; it < iters; ++it) {
+            RunSteps(pi, nullptr, &ev);
+            check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+            for (size_t i = 0; i < ns; ++i) {
+                float ms = 0;
+                check(hipEventElapsedTime(&ms, ev[i], ev[i + 1]), "hipEventElapsedTime");
+                out[i].ms += ms / float(iters);
+            }
+        }
+    } catch (...) {
+        for (auto& e : ev) (void)hipEventDestroy(e);
+        throw;
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return out;
+}
+
+void DeviceModel::InferHost(PlanInstance& pi, const std::vector<const void*>& inputs, const std::vector<size_t>& in_bytes,
+                            const std::vector<void*>& outputs, const std::vector<size_t>& out_bytes) {
+    check(hipSetDevice(device_), "hipSetDevice");
+    hipEvent_t slot_ev[kSlots];
+    for (auto& e : slot_ev) check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+    bool slot_used[kSlots] = {false, false, false, false};
+    int slot = 0;
+    auto fail_cleanup = [&] { for (auto& e : slot_ev) (void)hipEventDestroy(e); };
+    try {
+        // ---- H2D: caller memory -> pinned ring -> device, CPU copy of chunk k+1 overlaps the DMA of chunk k ----
+        for (size_t i = 0; i < pi.plan.inputs.size(); ++i) {
+            const View& v = pi.plan.inputs[i].view;
+            char* dst = reinterpret_cast<char*>(pi.buffers[size_t(v.buf)]);
+            const size_t need = size_t(v.numel()) * sizeof(float);
+            const size_t have = inputs[i] ? std::min(in_bytes[i], need) : 0;
+            for (size_t off = 0; off < have; off += kChunk) {
+                const size_t nb = std::min(kChunk, have - off);
+                if (slot_used[slot]) check(hipEventSynchronize(slot_ev[slot]), "hipEventSynchronize");
+                char* stage = static_cast<char*>(pinned_) + size_t(slot) * kChunk;
+                std::memcpy(stage, static_cast<const char*>(inputs[i]) + off, nb);
+                check(hipMemcpyAsync(dst + off, stage, nb, hipMemcpyHostToDevice, stream_), "hipMemcpyAsync(H2D)");
+                check(hipEventRecord(slot_ev[slot], stream_), "hipEventRecord");
+                slot_used[slot] = true;
+                slot = (slot + 1) % kSlots;
+            }
+            if (have < need) check(hipMemsetAsync(dst + have, 0, need - have, stream_), "hipMemsetAsync");
+        }
+        Enqueue(pi);
+        // ---- D2H -------------------------------------------------------------------------------------------
+        for (size_t i = 0; i < outputs.size() && i < pi.plan.outputs.size(); ++i) {
+            if (!outputs[i] || out_bytes[i] == 0) continue;
+            const View& v = pi.plan.outputs[i].view;
+            const char* src = reinterpret_cast<const char*>(pi.buffers[size_t(v.buf)]);
+            const size_t produced = size_t(v.numel()) * sizeof(float);
+            const size_t nbytes = std::min(out_bytes[i], produced);
+            for (size_t off = 0; off < nbytes; off += kChunk * kSlots) {
+                const size_t nb = std::min(kChunk * kSlots, nbytes - off);
+                check(hipStreamSynchronize(stream_), "hipStreamSynchronize");     // ring is free again
+                check(hipMemcpyAsync(pinned_, src + off, nb, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(D2H)");
+                check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+                std::memcpy(static_cast<char*>(outputs[i]) + off, pinned_, nb);
+            }
+            if (out_bytes[i] > nbytes) std::memset(static_cast<char*>(outputs[i]) + nbytes, 0, out_bytes[i] - nbytes);
+        }
+        check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+    } catch (...) {
+        (void)hipStreamSynchronize(stream_);
+        fail_cleanup();
+        throw;
+    }
+    fail_cleanup();
+}
+
+}  // namespace ie

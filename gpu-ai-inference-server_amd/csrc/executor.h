@@ -1,0 +1,85 @@
+// Device-side model: weights resident in HBM, planned activation buffers, one hipGraph per input shape.
+//
+// MI355X-native replacement for the Ort::Session the reference owns per model
+// (inference_engine/src/model.cpp:706-714, created at :847, run at :1264-1270).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "onnx_reader.h"
+#include "plan.h"
+
+namespace ie {
+
+struct StepTiming {
+    std::string name, kernel;
+    double ms = 0, flops = 0, bytes = 0;
+};
+
+struct PlanInstance {
+    Plan plan;
+    std::vector<float*> buffers;       // device activation buffers (plan.buffer_floats)
+    hipGraphExec_t graph_exec = nullptr;
+    bool graph_ready = false;
+};
+
+class DeviceModel {
+public:
+    // Parses nothing itself: takes the decoded graph. Throws std::runtime_error (never falls back to a CPU path).
+    DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id);
+    ~DeviceModel();
+    DeviceModel(const DeviceModel&) = delete;
+    DeviceModel& operator=(const DeviceModel&) = delete;
+
+    // Get (or build: plan + allocate + capture) the instance for these input shapes.
+    PlanInstance& Prepare(const std::vector<std::vector<int64_t>>& shapes);
+    // Enqueue one forward of `pi` on the model stream (graph replay when available).
+    void Enqueue(PlanInstance& pi);
+    // Eager forward with hipEvents around every launch; per-step times in ms (averaged over iters).
+    std::vector<StepTiming> Profile(PlanInstance& pi, int iters);
+    void Synchronize();
+
+    // Host-buffer inference (the ModelInfer path): inputs[i] has in_bytes[i] valid bytes (shorter payloads are
+    // zero-extended like the reference's zero-initialised Tensor), outputs[i] receives min(out_bytes[i], produced)
+    // bytes and the rest of the caller buffer is zero-filled.
+    void InferHost(PlanInstance& pi, const std::vector<const void*>& inputs, const std::vector<size_t>& in_bytes,
+                   const std::vector<void*>& outputs, const std::vector<size_t>& out_bytes);
+
+    hipStream_t stream() const { return stream_; }
+    int device() const { return device_; }
+    float* weights() const { return d_weights_; }
+    size_t weight_bytes() const { return weight_floats_ * sizeof(float); }
+    size_t device_bytes() const { return device_bytes_; }
+    std::mutex& mutex() { return mu_; }
+    PlanInstance* current() { return current_; }
+
+private:
+    void RunSteps(PlanInstance& pi, std::vector<StepTiming>* timings, std::vector<hipEvent_t>* events);
+    void LaunchStep(const PlanInstance& pi, const Step& s);
+
+    std::shared_ptr<const OnnxModel> model_;
+    int device_ = 0;
+    hipStream_t stream_ = nullptr;
+    float* d_weights_ = nullptr;
+    size_t weight_floats_ = 0;
+    size_t device_bytes_ = 0;
+    bool use_graph_ = true;
+    std::map<std::vector<int64_t>, std::unique_ptr<PlanInstance>> plans_;
+    PlanInstance* current_ = nullptr;
+    void* pinned_ = nullptr;           // pinned host staging ring for H2D/D2H
+    size_t pinned_bytes_ = 0;
+    std::mutex mu_;
+};
+
+// Device queries behind IsCudaAvailable / GetDeviceCount / GetDeviceInfo / GetMemoryInfo
+// (reference: inference_engine/src/cuda_utils.cu:17-57, 152-176).
+int HipDeviceCount();
+std::string HipDeviceInfo(int device_id);
+bool HipMemoryInfo(int device_id, size_t* total, size_t* free_b);
+
+}  // namespace ie

@@ -1,0 +1,56 @@
+// Launchers of the hand-written gfx950 kernels (definitions in kernels.hip).
+// Every launcher only enqueues work on `stream` (no allocation, no synchronisation), so a whole forward
+// pass can be captured into a hipGraph (executor.cpp).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace ie {
+
+// Strided activation operand: element (n, y, x, c) lives at  base + n*sn + y*sh + x*sw + c*sc.
+struct TensorArg {
+    float* p = nullptr;
+    int n = 0, h = 0, w = 0, c = 0;
+    int64_t sn = 0, sh = 0, sw = 0, sc = 0;
+};
+
+struct ConvArgs {
+    TensorArg in, out;                 // out is always NHWC (sc == 1)
+    const float* w = nullptr;          // [Cout][kh][kw][Cin]
+    const float* bias = nullptr;       // [Cout] or null
+    const float* pre_scale = nullptr;  // [Cin] or null: x <- x*scale + shift (then ReLU if pre_relu) before the conv
+    const float* pre_shift = nullptr;
+    int kh = 1, kw = 1, sh = 1, sw = 1, pt = 0, pl = 0;
+    int pre_relu = 0, relu = 0;
+};
+
+struct PoolArgs {
+    TensorArg in, out;                 // NHWC
+    int kh = 1, kw = 1, sh = 1, sw = 1, pt = 0, pl = 0, pb = 0, pr = 0;
+    int is_max = 0, count_include_pad = 0;
+};
+
+struct EltArgs {
+    TensorArg a, b, out;               // b.p == null: no second operand
+    const float* scale = nullptr;      // per channel, or null
+    const float* shift = nullptr;
+    int relu = 0;
+};
+
+// vec: 1 = float4 NHWC operand staging, 0 = scalar gather staging.  tile: index into kIgemmTiles.
+hipError_t LaunchConvIgemm(const ConvArgs& a, int tile, int vec, hipStream_t stream);
+hipError_t LaunchConvNaive(const ConvArgs& a, hipStream_t stream);
+hipError_t LaunchPool(const PoolArgs& a, hipStream_t stream);
+// out[n, c] = mean over (y, x) of f(in[n, y, x, c]),  f = optional scale/shift/ReLU prologue
+hipError_t LaunchGlobalAvgPool(const TensorArg& in, const TensorArg& out, const float* pre_scale, const float* pre_shift,
+                               int pre_relu, hipStream_t stream);
+hipError_t LaunchEltwise(const EltArgs& a, hipStream_t stream);
+hipError_t LaunchCopy(const TensorArg& in, const TensorArg& out, hipStream_t stream);
+// result[i] = a[i] + b[i]  (the reference's only authored kernel: cuda_utils.cu:10-15)
+hipError_t LaunchVectorAdd(const float* a, const float* b, float* result, int64_t n, hipStream_t stream);
+
+// One-time per-process setup (raises the dynamic-LDS limit of the igemm kernels).
+hipError_t InitKernels();
+
+}  // namespace ie

@@ -1,0 +1,556 @@
+// Hand-written gfx950 (CDNA4, wave64) kernels for the ONNX operator set the in-scope graphs execute.
+// They replace the device work ONNX Runtime's CUDA EP performs inside `Ort::Session::Run`
+// (reference call site: inference_engine/src/model.cpp:1264-1270).
+//
+//   conv_igemm_kernel   Conv / Gemm / MatMul as an implicit GEMM on the f32 matrix cores
+//                       (v_mfma_f32_32x32x2_f32: exact fp32 FMA chain, 64 FLOP/clk/SIMD).
+//                       M = N*OH*OW output pixels, N = Cout, K = kh*kw*Cin.
+//                       * NHWC activations: channels are the contiguous GEMM-K axis, so operand staging is
+//                         coalesced 16 B/lane global loads -> registers -> LDS
+//                       * folded BatchNorm + ReLU of the *input* (DenseNet pre-activation) is applied while
+//                         staging the A operand, bias + ReLU on the accumulators in the epilogue
+//                       * the epilogue writes Cout channels at a channel offset of a wider NHWC row, which is
+//                         what makes Concat free
+//                       * LDS tiles are [rows][BK+4] floats: with pitch/4 odd every ds_read_b128 of a
+//                         16-lane group hits 16 distinct 16-B slots (conflict-free), one b128 read feeds 4 MFMAs
+//                       * register-staged double buffering: global loads of K-tile t+1 are in flight while the
+//                         MFMAs of K-tile t run; one barrier per K-tile
+//                       * blockIdx is remapped so each XCD (private 4 MiB L2) owns a contiguous run of M-tiles:
+//                         the 3x3 halo rows shared by neighbouring tiles are then L2 hits
+//   pool / gap / eltwise / copy: bandwidth-bound NHWC kernels, 16 B per lane where alignment allows.
+#include <hip/hip_runtime.h>
+
+#include "igemm_tiles.h"
+#include "kernels.h"
+
+namespace ie {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+// implicit-GEMM convolution on v_mfma_f32_32x32x2_f32
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, bool VEC>
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs a, const int tiles_n, const int num_tiles) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int BK = kIgemmBK;
+    constexpr int LDP = BK + kIgemmLdsPad;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    static_assert(TM >= 1 && TN >= 1 && BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "bad tile");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const sA = smem;                   // [2][BM][LDP]
+    float* const sB = smem + 2 * BM * LDP;    // [2][BN][LDP]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm_i = wave / WN, wn_i = wave % WN;
+    const int r = lane & 31, hh = lane >> 5;
+
+    // XCD-aware bijective remap: blocks b, b+8, b+16.. share an XCD; give each XCD a contiguous tile range.
+    int tile_m, tile_n;
+    {
+        const int bid = blockIdx.x;
+        const int q = num_tiles >> 3, rem = num_tiles & 7, xcd = bid & 7;
+        const int swz = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+        tile_n = swz % tiles_n;
+        tile_m = swz / tiles_n;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int Cin = a.in.c, H = a.in.h, W = a.in.w;
+    const int OH = a.out.h, OW = a.out.w, Cout = a.out.c;
+    const int M = a.out.n * OH * OW;
+    const int Ktot = a.kh * a.kw * Cin;
+    const float* __restrict__ in = a.in.p;
+    const float* __restrict__ wgt = a.w;
+    const bool has_pre = a.pre_scale != nullptr;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto compute = [&](int buf) {
+        const float* A = sA + buf * BM * LDP + (wm_i * TM * 32 + r) * LDP + hh * 4;
+        const float* B = sB + buf * BN * LDP + (wn_i * TN * 32 + r) * LDP + hh * 4;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(A + i * 32 * LDP + kk * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(B + j * 32 * LDP + kk * 8);
+            // lanes 0-31 carry k = kk*8+e, lanes 32-63 carry k = kk*8+4+e, identically for A and B,
+            // so the four K=2 MFMAs together cover the 8 k-values of this chunk.
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if constexpr (VEC) {
+        // ---- float4 staging: thread owns column-quad `c4` of rows {rw + i*ROWS_PER_PASS} ----------------
+        constexpr int ROWS_PER_PASS = NT / 8;
+        constexpr int A_IT = BM / ROWS_PER_PASS, B_IT = BN / ROWS_PER_PASS;
+        static_assert(A_IT >= 1 && B_IT >= 1, "tile too small for the thread count");
+        const int c4 = (tid & 7) * 4;
+        const int rw = tid >> 3;
+        const int cblocks = (Cin + BK - 1) / BK;
+        const int KT = a.kh * a.kw * cblocks;
+
+        int iy0[A_IT], ix0[A_IT];
+        int64_t rbase[A_IT];
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int m = m0 + rw + i * ROWS_PER_PASS;
+            if (m < M) {
+                const int b = m / (OH * OW);
+                const int rem = m - b * (OH * OW);
+                const int oy = rem / OW, ox = rem - oy * OW;
+                iy0[i] = oy * a.sh - a.pt;
+                ix0[i] = ox * a.sw - a.pl;
+                rbase[i] = int64_t(b) * a.in.sn;
+            } else {
+                iy0[i] = -(1 << 28);    // every tap falls outside -> zero rows
+                ix0[i] = 0;
+                rbase[i] = 0;
+            }
+        }
+        f32x4 ra[A_IT], rb[B_IT];
+        auto load_tile = [&](int kt) {
+            const int tap = kt / cblocks;
+            const int c = (kt - tap * cblocks) * BK + c4;
+            const int ky = tap / a.kw, kx = tap - ky * a.kw;
+            const bool cok = c < Cin;
+            f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
+            if (has_pre) {
+                const int cc = cok ? c : 0;
+                s4 = *reinterpret_cast<const f32x4*>(a.pre_scale + cc);
+                t4 = *reinterpret_cast<const f32x4*>(a.pre_shift + cc);
+            }
+            bool ok[A_IT];
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const int iy = iy0[i] + ky, ix = ix0[i] + kx;
+                ok[i] = cok && unsigned(iy) < unsigned(H) && unsigned(ix) < unsigned(W);
+                // unconditional load from a clamped address (keeps the loads batched; no per-load branch)
+                const int64_t off = ok[i] ? rbase[i] + int64_t(iy) * a.in.sh + int64_t(ix) * a.in.sw + c : 0;
+                ra[i] = *reinterpret_cast<const f32x4*>(in + off);
+            }
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) {
+                const int n = n0 + rw + i * ROWS_PER_PASS;
+                const bool bok = cok && n < Cout;
+                const int64_t off = bok ? int64_t(n) * Ktot + tap * Cin + c : 0;
+                f32x4 v = *reinterpret_cast<const f32x4*>(wgt + off);
+                if (!bok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                rb[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                f32x4 v = ra[i];
+                if (has_pre) {
+                    v = v * s4 + t4;
+                    if (a.pre_relu) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                }
+                if (!ok[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};   // zero padding is applied AFTER the activation
+                ra[i] = v;
+            }
+        };
+        auto store_tile = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i)
+                *reinterpret_cast<f32x4*>(sA + buf * BM * LDP + (rw + i * ROWS_PER_PASS) * LDP + c4) = ra[i];
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i)
+                *reinterpret_cast<f32x4*>(sB + buf * BN * LDP + (rw + i * ROWS_PER_PASS) * LDP + c4) = rb[i];
+        };
+
+        load_tile(0);
+        store_tile(0);
+        __syncthreads();
+        for (int kt = 0; kt < KT; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < KT) load_tile(kt + 1);
+            compute(buf);
+            if (kt + 1 < KT) store_tile(buf ^ 1);
+            __syncthreads();
+        }
+    } else {
+        // ---- scalar gather staging: any Cin, any input strides (NCHW stem) ------------------------------
+        constexpr int ROWS_PER_PASS = NT / BK;
+        constexpr int A_IT = BM / ROWS_PER_PASS, B_IT = BN / ROWS_PER_PASS;
+        int64_t* const s_rbase = reinterpret_cast<int64_t*>(smem + 2 * (BM + BN) * LDP);
+        int* const s_iy0 = reinterpret_cast<int*>(s_rbase + BM);
+        int* const s_ix0 = s_iy0 + BM;
+        for (int row = tid; row < BM; row += NT) {
+            const int m = m0 + row;
+            if (m < M) {
+                const int b = m / (OH * OW);
+                const int rem = m - b * (OH * OW);
+                const int oy = rem / OW, ox = rem - oy * OW;
+                s_iy0[row] = oy * a.sh - a.pt;
+                s_ix0[row] = ox * a.sw - a.pl;
+                s_rbase[row] = int64_t(b) * a.in.sn;
+            } else {
+                s_iy0[row] = -(1 << 28);
+                s_ix0[row] = 0;
+                s_rbase[row] = 0;
+            }
+        }
+        __syncthreads();
+        const int col = tid & (BK - 1);
+        const int rw = tid / BK;
+        const int KT = (Ktot + BK - 1) / BK;
+        float ra[A_IT], rb[B_IT];
+        auto load_tile = [&](int kt) {
+            const int k = kt * BK + col;
+            const bool kok = k < Ktot;
+            const int kk = kok ? k : 0;
+            const int tap = kk / Cin;
+            const int c = kk - tap * Cin;
+            const int ky = tap / a.kw, kx = tap - ky * a.kw;
+            float s = 1.f, t = 0.f;
+            if (has_pre) { s = a.pre_scale[c]; t = a.pre_shift[c]; }
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const int row = rw + i * ROWS_PER_PASS;
+                const int iy = s_iy0[row] + ky, ix = s_ix0[row] + kx;
+                const bool ok = kok && unsigned(iy) < unsigned(H) && unsigned(ix) < unsigned(W);
+                const int64_t off = ok ? s_rbase[row] + int64_t(iy) * a.in.sh + int64_t(ix) * a.in.sw + int64_t(c) * a.in.sc : 0;
+                float v = in[off];
+                if (has_pre) { v = v * s + t; if (a.pre_relu) v = fmaxf(v, 0.f); }
+                ra[i] = ok ? v : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) {
+                const int n = n0 + rw + i * ROWS_PER_PASS;
+                const bool bok = kok && n < Cout;
+                const float v = wgt[bok ? int64_t(n) * Ktot + k : 0];
+                rb[i] = bok ? v : 0.f;
+            }
+        };
+        auto store_tile = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) sA[buf * BM * LDP + (rw + i * ROWS_PER_PASS) * LDP + col] = ra[i];
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) sB[buf * BN * LDP + (rw + i * ROWS_PER_PASS) * LDP + col] = rb[i];
+        };
+        load_tile(0);
+        store_tile(0);
+        __syncthreads();
+        for (int kt = 0; kt < KT; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < KT) load_tile(kt + 1);
+            compute(buf);
+            if (kt + 1 < KT) store_tile(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: bias + ReLU, store Cout channels at the view's channel offset --------------------------
+    float* __restrict__ out = a.out.p;
+    const int64_t opitch = a.out.sw;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn_i * TN + j) * 32 + r;
+        const bool nok = n < Cout;
+        const float bv = (a.bias != nullptr && nok) ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + (wm_i * TM + i) * 32 + 4 * hh;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = mb + (e & 3) + 8 * (e >> 2);
+                float v = acc[i][j][e] + bv;
+                if (a.relu) v = fmaxf(v, 0.f);
+                if (nok && m < M) out[int64_t(m) * opitch + n] = v;
+            }
+        }
+    }
+}
+
+template <int T, bool VEC>
+static size_t igemm_lds_bytes() {
+    constexpr IgemmTile t = kIgemmTiles[T];
+    size_t b = size_t(2) * (t.bm + t.bn) * (kIgemmBK + kIgemmLdsPad) * sizeof(float);
+    if (!VEC) b += size_t(t.bm) * (sizeof(int64_t) + 2 * sizeof(int));
+    return b;
+}
+
+template <int T, bool VEC>
+static hipError_t launch_igemm_t(const ConvArgs& a, hipStream_t stream) {
+    constexpr IgemmTile t = kIgemmTiles[T];
+    const int64_t M = int64_t(a.out.n) * a.out.h * a.out.w;
+    const int tiles_m = int((M + t.bm - 1) / t.bm), tiles_n = (a.out.c + t.bn - 1) / t.bn;
+    const int num_tiles = tiles_m * tiles_n;
+    conv_igemm_kernel<t.bm, t.bn, t.wm, t.wn, VEC>
+        <<<dim3(num_tiles), dim3(64 * t.wm * t.wn), igemm_lds_bytes<T, VEC>(), stream>>>(a, tiles_n, num_tiles);
+    return hipGetLastError();
+}
+
+template <int T, bool VEC>
+static hipError_t init_igemm_t() {
+    constexpr IgemmTile t = kIgemmTiles[T];
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<t.bm, t.bn, t.wm, t.wn, VEC>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, int(igemm_lds_bytes<T, VEC>()));
+}
+
+hipError_t LaunchConvIgemm(const ConvArgs& a, int tile, int vec, hipStream_t stream) {
+    if (a.out.sc != 1) return hipErrorInvalidValue;
+    if (int64_t(a.out.n) * a.out.h * a.out.w >= (int64_t(1) << 31)) return hipErrorInvalidValue;
+    if (vec) {
+        if (a.in.sc != 1 || (a.in.c & 3) || (a.in.sw & 3) || (a.in.sh & 3) || (a.in.sn & 3) ||
+            (reinterpret_cast<uintptr_t>(a.in.p) & 15) || (reinterpret_cast<uintptr_t>(a.w) & 15))
+            return hipErrorInvalidValue;
+        if (a.pre_scale && ((reinterpret_cast<uintptr_t>(a.pre_scale) & 15) || (reinterpret_cast<uintptr_t>(a.pre_shift) & 15)))
+            return hipErrorInvalidValue;
+    }
+#define IE_CASE(T)                                                                                  \
+    case T: return vec ? launch_igemm_t<T, true>(a, stream) : launch_igemm_t<T, false>(a, stream);
+    switch (tile) {
+        IE_CASE(0) IE_CASE(1) IE_CASE(2) IE_CASE(3) IE_CASE(4) IE_CASE(5) IE_CASE(6)
+        default: return hipErrorInvalidValue;
+    }
+#undef IE_CASE
+}
+
+hipError_t InitKernels() {
+    hipError_t e;
+#define IE_INIT(T)                                                     \
+    if ((e = init_igemm_t<T, true>()) != hipSuccess) return e;         \
+    if ((e = init_igemm_t<T, false>()) != hipSuccess) return e;
+    IE_INIT(0) IE_INIT(1) IE_INIT(2) IE_INIT(3) IE_INIT(4) IE_INIT(5) IE_INIT(6)
+#undef IE_INIT
+    return hipSuccess;
+}
+
+// ------------------------------------------------------------------------------------------------
+// naive convolution: one thread per output element (tiny / odd shapes, on-device cross-check)
+// ------------------------------------------------------------------------------------------------
+__global__ void conv_naive_kernel(const ConvArgs a, const int64_t total) {
+    const int64_t idx = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int Cout = a.out.c, OW = a.out.w, OH = a.out.h, Cin = a.in.c;
+    const int n = int(idx % Cout);
+    int64_t m = idx / Cout;
+    const int ox = int(m % OW); m /= OW;
+    const int oy = int(m % OH);
+    const int b = int(m / OH);
+    float acc = 0.f;
+    const float* wrow = a.w + int64_t(n) * a.kh * a.kw * Cin;
+    for (int ky = 0; ky < a.kh; ++ky) {
+        const int iy = oy * a.sh - a.pt + ky;
+        if (unsigned(iy) >= unsigned(a.in.h)) continue;
+        for (int kx = 0; kx < a.kw; ++kx) {
+            const int ix = ox * a.sw - a.pl + kx;
+            if (unsigned(ix) >= unsigned(a.in.w)) continue;
+            const float* px = a.in.p + int64_t(b) * a.in.sn + int64_t(iy) * a.in.sh + int64_t(ix) * a.in.sw;
+            const float* wp = wrow + (ky * a.kw + kx) * Cin;
+            for (int c = 0; c < Cin; ++c) {
+                float v = px[int64_t(c) * a.in.sc];
+                if (a.pre_scale) { v = v * a.pre_scale[c] + a.pre_shift[c]; if (a.pre_relu) v = fmaxf(v, 0.f); }
+                acc = fmaf(v, wp[c], acc);
+            }
+        }
+    }
+    if (a.bias) acc += a.bias[n];
+    if (a.relu) acc = fmaxf(acc, 0.f);
+    a.out.p[int64_t(b) * a.out.sn + int64_t(oy) * a.out.sh + int64_t(ox) * a.out.sw + n] = acc;
+}
+
+hipError_t LaunchConvNaive(const ConvArgs& a, hipStream_t stream) {
+    const int64_t total = int64_t(a.out.n) * a.out.h * a.out.w * a.out.c;
+    if (total == 0) return hipSuccess;
+    const int64_t blocks = (total + 255) / 256;
+    if (blocks >= (int64_t(1) << 31)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(conv_naive_kernel, dim3(unsigned(blocks)), dim3(256), 0, stream, a, total);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// pooling (NHWC).  V = channels per thread (4 -> 16 B/lane).
+// ------------------------------------------------------------------------------------------------
+template <int V>
+__global__ void pool_kernel(const PoolArgs a, const int64_t total) {
+    const int64_t idx = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int CV = a.out.c / V;
+    const int c = int(idx % CV) * V;
+    int64_t m = idx / CV;
+    const int ox = int(m % a.out.w); m /= a.out.w;
+    const int oy = int(m % a.out.h);
+    const int b = int(m / a.out.h);
+    float acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = a.is_max ? -INFINITY : 0.f;
+    int cnt = 0;
+    for (int ky = 0; ky < a.kh; ++ky) {
+        const int iy = oy * a.sh - a.pt + ky;
+        if (iy >= a.in.h + a.pb) break;                      // beyond the padded extent (ceil_mode)
+        for (int kx = 0; kx < a.kw; ++kx) {
+            const int ix = ox * a.sw - a.pl + kx;
+            if (ix >= a.in.w + a.pr) break;
+            const bool inside = unsigned(iy) < unsigned(a.in.h) && unsigned(ix) < unsigned(a.in.w);
+            if (inside || a.count_include_pad) ++cnt;
+            if (!inside) continue;
+            const float* p = a.in.p + int64_t(b) * a.in.sn + int64_t(iy) * a.in.sh + int64_t(ix) * a.in.sw + c;
+            float x[V];
+            if constexpr (V == 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+                x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
+            } else x[0] = p[0];
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[v] = a.is_max ? fmaxf(acc[v], x[v]) : acc[v] + x[v];
+        }
+    }
+    float* o = a.out.p + int64_t(b) * a.out.sn + int64_t(oy) * a.out.sh + int64_t(ox) * a.out.sw + c;
+    const float inv = (!a.is_max && cnt > 0) ? 1.f / float(cnt) : 1.f;
+    if constexpr (V == 4) {
+        f32x4 t;
+        t.x = a.is_max ? acc[0] : acc[0] * inv; t.y = a.is_max ? acc[1] : acc[1] * inv;
+        t.z = a.is_max ? acc[2] : acc[2] * inv; t.w = a.is_max ? acc[3] : acc[3] * inv;
+        *reinterpret_cast<f32x4*>(o) = t;
+    } else o[0] = a.is_max ? acc[0] : acc[0] * inv;
+}
+
+static bool aligned4(const TensorArg& t) {
+    return t.sc == 1 && !(t.c & 3) && !(t.sw & 3) && !(t.sh & 3) && !(t.sn & 3) && !(reinterpret_cast<uintptr_t>(t.p) & 15);
+}
+
+hipError_t LaunchPool(const PoolArgs& a, hipStream_t stream) {
+    if (a.in.sc != 1 || a.out.sc != 1) return hipErrorInvalidValue;
+    const bool v4 = aligned4(a.in) && aligned4(a.out);
+    const int64_t total = int64_t(a.out.n) * a.out.h * a.out.w * (a.out.c / (v4 ? 4 : 1));
+    if (total == 0) return hipSuccess;
+    const int64_t blocks = (total + 255) / 256;
+    if (blocks >= (int64_t(1) << 31)) return hipErrorInvalidValue;
+    if (v4) hipLaunchKernelGGL(pool_kernel<4>, dim3(unsigned(blocks)), dim3(256), 0, stream, a, total);
+    else hipLaunchKernelGGL(pool_kernel<1>, dim3(unsigned(blocks)), dim3(256), 0, stream, a, total);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// global average pool with fused scale/shift/ReLU prologue.  Block = 64 channels x 4 pixel groups.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gap_kernel(const TensorArg in, const TensorArg out, const float* __restrict__ ps,
+                                                   const float* __restrict__ pt, const int pre_relu) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int b = blockIdx.y;
+    const int HW = in.h * in.w;
+    float s = 1.f, t = 0.f;
+    const bool cok = c < in.c;
+    if (ps && cok) { s = ps[c]; t = pt[c]; }
+    float acc = 0.f;
+    if (cok)
+        for (int p = g; p < HW; p += 4) {
+            const int y = p / in.w, x = p - y * in.w;
+            float v = in.p[int64_t(b) * in.sn + int64_t(y) * in.sh + int64_t(x) * in.sw + c];
+            if (ps) { v = v * s + t; }
+            if (pre_relu) v = fmaxf(v, 0.f);
+            acc += v;
+        }
+    red[g][cl] = acc;
+    __syncthreads();
+    if (g == 0 && cok) {
+        const float tot = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        out.p[int64_t(b) * out.sn + c] = tot / float(HW);
+    }
+}
+
+hipError_t LaunchGlobalAvgPool(const TensorArg& in, const TensorArg& out, const float* pre_scale, const float* pre_shift,
+                               int pre_relu, hipStream_t stream) {
+    if (in.sc != 1 || out.sc != 1) return hipErrorInvalidValue;
+    if (in.n == 0 || in.c == 0) return hipSuccess;
+    hipLaunchKernelGGL(gap_kernel, dim3((in.c + 63) / 64, in.n), dim3(256), 0, stream, in, out, pre_scale, pre_shift, pre_relu);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// elementwise: out = relu?( scale[c]*a + shift[c] (+ b) )   (stand-alone BN / ReLU / residual Add)
+// ------------------------------------------------------------------------------------------------
+__global__ void eltwise_kernel(const EltArgs a, const int64_t total) {
+    const int64_t idx = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = int(idx % a.out.c);
+    int64_t m = idx / a.out.c;
+    const int x = int(m % a.out.w); m /= a.out.w;
+    const int y = int(m % a.out.h);
+    const int b = int(m / a.out.h);
+    float v = a.a.p[int64_t(b) * a.a.sn + int64_t(y) * a.a.sh + int64_t(x) * a.a.sw + int64_t(c) * a.a.sc];
+    if (a.scale) v = v * a.scale[c] + a.shift[c];
+    if (a.b.p) v += a.b.p[int64_t(b) * a.b.sn + int64_t(y) * a.b.sh + int64_t(x) * a.b.sw + int64_t(c) * a.b.sc];
+    if (a.relu) v = fmaxf(v, 0.f);
+    a.out.p[int64_t(b) * a.out.sn + int64_t(y) * a.out.sh + int64_t(x) * a.out.sw + int64_t(c) * a.out.sc] = v;
+}
+
+hipError_t LaunchEltwise(const EltArgs& a, hipStream_t stream) {
+    const int64_t total = int64_t(a.out.n) * a.out.h * a.out.w * a.out.c;
+    if (total == 0) return hipSuccess;
+    const int64_t blocks = (total + 255) / 256;
+    if (blocks >= (int64_t(1) << 31)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(eltwise_kernel, dim3(unsigned(blocks)), dim3(256), 0, stream, a, total);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// strided copy (layout transforms NCHW<->NHWC, channel-slice copies).  Threads walk the OUTPUT in its
+// memory order so the stores are coalesced.
+// ------------------------------------------------------------------------------------------------
+__global__ void copy_kernel(const TensorArg in, const TensorArg out, const int out_c_fastest, const int64_t total) {
+    const int64_t idx = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    int b, c, y, x;
+    int64_t m = idx;
+    if (out_c_fastest) {
+        c = int(m % out.c); m /= out.c;
+        x = int(m % out.w); m /= out.w;
+        y = int(m % out.h); b = int(m / out.h);
+    } else {
+        x = int(m % out.w); m /= out.w;
+        y = int(m % out.h); m /= out.h;
+        c = int(m % out.c); b = int(m / out.c);
+    }
+    out.p[int64_t(b) * out.sn + int64_t(y) * out.sh + int64_t(x) * out.sw + int64_t(c) * out.sc] =
+        in.p[int64_t(b) * in.sn + int64_t(y) * in.sh + int64_t(x) * in.sw + int64_t(c) * in.sc];
+}
+
+hipError_t LaunchCopy(const TensorArg& in, const TensorArg& out, hipStream_t stream) {
+    const int64_t total = int64_t(out.n) * out.h * out.w * out.c;
+    if (total == 0) return hipSuccess;
+    const int64_t blocks = (total + 255) / 256;
+    if (blocks >= (int64_t(1) << 31)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(copy_kernel, dim3(unsigned(blocks)), dim3(256), 0, stream, in, out, out.sc == 1 ? 1 : 0, total);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// vector add (parity with the reference's smoke-test kernel; grid-stride, 16 B per lane when aligned)
+// ------------------------------------------------------------------------------------------------
+__global__ void vector_add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ r, const int64_t n) {
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) r[i] = a[i] + b[i];
+}
+
+hipError_t LaunchVectorAdd(const float* a, const float* b, float* result, int64_t n, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    const int64_t blocks = (n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048;
+    hipLaunchKernelGGL(vector_add_kernel, dim3(unsigned(blocks)), dim3(256), 0, stream, a, b, result, n);
+    return hipGetLastError();
+}
+
+}  // namespace ie

@@ -1,0 +1,843 @@
+#include "plan.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <map>
+#include <set>
+#include <sstream>
+#include <stdexcept>
+
+#include "igemm_tiles.h"
+
+namespace ie {
+namespace {
+
+[[noreturn]] void fail(const std::string& msg) { throw std::runtime_error(msg); }
+
+struct Val {
+    std::string name;
+    std::vector<int64_t> dims;          // resolved ONNX dims
+    int64_t n = 0, c = 0, h = 1, w = 1;
+    int producer = -1;                  // LNode index, -1 = graph input
+    bool is_input = false, is_output = false, input_nchw = false;
+    int parent = -1;                    // concat parent value
+    int64_t parent_off = 0;
+    int root = -1;
+    int64_t abs_off = 0;
+    int buf = -1;
+};
+
+enum LKind { L_CONV, L_AFFINE, L_RELU, L_ADD, L_CONCAT, L_MAXPOOL, L_AVGPOOL, L_GAP, L_ALIAS, L_COPY };
+
+struct LNode {
+    LKind kind;
+    std::string name;
+    std::vector<int> in;
+    int out = -1;
+    int kh = 1, kw = 1, sh = 1, sw = 1, pt = 0, pl = 0, pb = 0, pr = 0;
+    bool count_include_pad = false;
+    std::vector<float> w, bias;         // conv: w packed [Cout][kh][kw][Cin]
+    std::vector<float> s, t;            // affine
+    bool has_pre = false, pre_relu = false, relu = false;
+    std::vector<float> pre_s, pre_t;
+    bool dead = false;
+};
+
+struct Lowering {
+    const OnnxModel& m;
+    std::vector<Val> vals;
+    std::map<std::string, int> val_of;
+    std::vector<LNode> nodes;
+
+    explicit Lowering(const OnnxModel& mm) : m(mm) {}
+
+    int new_val(const std::string& name, const std::vector<int64_t>& dims) {
+        if (val_of.count(name)) fail("ONNX graph error: value defined twice: " + name);
+        Val v;
+        v.name = name;
+        v.dims = dims;
+        if (dims.size() == 4) { v.n = dims[0]; v.c = dims[1]; v.h = dims[2]; v.w = dims[3]; }
+        else if (dims.size() == 2) { v.n = dims[0]; v.c = dims[1]; }
+        else if (dims.size() == 3) { v.n = dims[0]; v.c = dims[1]; v.h = dims[2]; }
+        else if (dims.size() == 1) { v.n = 1; v.c = dims[0]; }
+        else fail("unsupported tensor rank " + std::to_string(dims.size()) + " for value " + name);
+        for (auto d : dims) if (d <= 0) fail("non-positive dimension in value " + name);
+        vals.push_back(v);
+        val_of[name] = int(vals.size()) - 1;
+        return int(vals.size()) - 1;
+    }
+    int get_val(const std::string& name) const {
+        auto it = val_of.find(name);
+        if (it == val_of.end()) fail("ONNX graph error: undefined value: " + name);
+        return it->second;
+    }
+    const OnnxTensor* init(const std::string& name) const {
+        auto it = m.initializers.find(name);
+        return it == m.initializers.end() ? nullptr : &it->second;
+    }
+    std::vector<int> consumers(int v) const {
+        std::vector<int> out;
+        for (size_t i = 0; i < nodes.size(); ++i)
+            if (!nodes[i].dead)
+                for (int x : nodes[i].in) if (x == v) { out.push_back(int(i)); break; }
+        return out;
+    }
+
+    // A constant that broadcasts along the channel axis of `x` (numpy rules): scalar, [C], [1,C], [C,1,1], [1,C,1,1].
+    bool per_channel_const(const OnnxTensor& t, const Val& x, std::vector<float>& out) const {
+        if (t.dtype != ONNX_FLOAT && t.dtype != ONNX_DOUBLE && t.dtype != ONNX_FLOAT16) return false;
+        int64_t n = t.numel();
+        if (n == 1) { out.assign(size_t(x.c), t.f[0]); return true; }
+        if (n != x.c) return false;
+        size_t rank = x.dims.size();
+        std::vector<int64_t> d = t.dims;
+        while (d.size() < rank) d.insert(d.begin(), 1);
+        if (d.size() != rank) return false;
+        for (size_t k = 0; k < rank; ++k) if (d[k] != (k == 1 ? x.c : 1)) {
+            // rank-1 value [C] against rank-2 x [N,C] puts C on the last axis, which IS the channel axis
+            return false;
+        }
+        out = t.f;
+        return true;
+    }
+};
+
+void conv_out_hw(int64_t h, int64_t w, const LNode& n, bool ceil_mode, int64_t& oh, int64_t& ow) {
+    auto f = [&](int64_t x, int k, int s, int p0, int p1) {
+        int64_t num = x + p0 + p1 - k;
+        if (num < 0) fail("kernel larger than padded input in node " + n.name);
+        return (ceil_mode ? (num + s - 1) / s : num / s) + 1;
+    };
+    oh = f(h, n.kh, n.sh, n.pt, n.pb);
+    ow = f(w, n.kw, n.sw, n.pl, n.pr);
+}
+
+void read_window_attrs(const OnnxNode& on, LNode& n, int64_t h, int64_t w, bool is_conv, const OnnxTensor* wt) {
+    std::vector<int64_t> ks = on.attr_ints("kernel_shape", {});
+    if (ks.empty() && is_conv && wt) ks = {wt->dims[2], wt->dims[3]};
+    if (ks.size() != 2) fail("node " + on.name + ": only 2-D kernels are supported");
+    n.kh = int(ks[0]); n.kw = int(ks[1]);
+    auto st = on.attr_ints("strides", {1, 1});
+    n.sh = int(st[0]); n.sw = int(st[1]);
+    auto dl = on.attr_ints("dilations", {1, 1});
+    if (dl[0] != 1 || dl[1] != 1) fail("node " + on.name + ": dilations != 1 are not supported");
+    auto pads = on.attr_ints("pads", {0, 0, 0, 0});
+    if (pads.size() != 4) fail("node " + on.name + ": pads must have 4 entries");
+    n.pt = int(pads[0]); n.pl = int(pads[1]); n.pb = int(pads[2]); n.pr = int(pads[3]);
+    auto ap = on.attrs.find("auto_pad");
+    if (ap != on.attrs.end() && !ap->second.s.empty() && ap->second.s != "NOTSET") {
+        const std::string& mode = ap->second.s;
+        if (mode == "VALID") n.pt = n.pl = n.pb = n.pr = 0;
+        else if (mode == "SAME_UPPER" || mode == "SAME_LOWER") {
+            auto same = [&](int64_t x, int k, int s, int& p0, int& p1) {
+                int64_t o = (x + s - 1) / s;
+                int64_t tot = std::max<int64_t>((o - 1) * s + k - x, 0);
+                int64_t a = tot / 2, b = tot - a;
+                if (mode == "SAME_UPPER") { p0 = int(a); p1 = int(b); } else { p0 = int(b); p1 = int(a); }
+            };
+            same(h, n.kh, n.sh, n.pt, n.pb);
+            same(w, n.kw, n.sw, n.pl, n.pr);
+        } else fail("node " + on.name + ": unsupported auto_pad " + mode);
+    }
+}
+
+int choose_tile(int64_t M, int64_t N) {
+    // Estimated time = rounds over the 256 CUs x tile area / tile efficiency.  Larger tiles reuse operands
+    // better (higher MFMA duty); smaller ones fill the chip when M*N is small.  A lone workgroup per CU
+    // cannot hide its own staging latency, so under-filled grids are charged a lower duty.
+    static const double eff[kNumIgemmTiles] = {1.00, 0.92, 0.78, 0.82, 0.62, 0.40, 0.84};
+    int best = -1;
+    double best_cost = 0;
+    for (int t = 0; t < kNumIgemmTiles; ++t) {
+        const IgemmTile& T = kIgemmTiles[t];
+        if (T.bn > 32 && N <= 32) continue;             // do not waste MFMA columns on zero padding
+        if (T.bn > 64 && N <= 64) continue;
+        double wgs = double((M + T.bm - 1) / T.bm) * double((N + T.bn - 1) / T.bn);
+        double per_cu = wgs / 256.0;
+        double rounds = std::max(1.0, 0.5 * (per_cu + std::ceil(per_cu)));
+        double duty = wgs >= 512 ? 0.9 : (wgs >= 256 ? 0.75 : 0.6);
+        double cost = rounds * double(T.bm) * T.bn / (eff[t] * duty);
+        if (best < 0 || cost < best_cost) { best = t; best_cost = cost; }
+    }
+    return best;
+}
+
+}  // namespace
+
+ModelInfo DescribeModel(const OnnxModel& m) {
+    ModelInfo info;
+    info.inputs = m.inputs;
+    info.outputs = m.outputs;
+    // EstimateModelMemoryUsage (model.cpp:979-1035): sum of I/O tensor bytes over positive dims + 10 MiB.
+    auto elem = [](int t) -> size_t {
+        switch (t) {
+            case ONNX_FLOAT: case ONNX_INT32: return 4;
+            case ONNX_INT64: return 8;
+            case ONNX_UINT8: case ONNX_INT8: case ONNX_BOOL: return 1;
+            case ONNX_FLOAT16: return 2;
+            default: return 4;
+        }
+    };
+    size_t total = 0;
+    for (auto* list : {&m.inputs, &m.outputs})
+        for (auto& vi : *list) {
+            size_t n = 1;
+            for (auto d : vi.dims) if (d > 0) n *= size_t(d);
+            total += n * elem(vi.elem_type);
+        }
+    info.memory_usage_bytes = total + size_t(10) * 1024 * 1024;
+    return info;
+}
+
+Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& input_shapes) {
+    Lowering L(m);
+    Plan plan;
+    if (input_shapes.size() != m.inputs.size())
+        fail("Expected " + std::to_string(m.inputs.size()) + " inputs, got " + std::to_string(input_shapes.size()));
+
+    // ---- graph inputs ---------------------------------------------------------------------------
+    for (size_t i = 0; i < m.inputs.size(); ++i) {
+        const auto& vi = m.inputs[i];
+        const auto& got = input_shapes[i];
+        if (vi.elem_type != ONNX_FLOAT) fail("Unsupported data type for input: " + vi.name);
+        if (!vi.dims.empty()) {
+            if (got.size() != vi.dims.size())
+                fail("Invalid rank for input: " + vi.name + " Got: " + std::to_string(got.size()) +
+                     " Expected: " + std::to_string(vi.dims.size()));
+            for (size_t k = 0; k < got.size(); ++k)
+                if (vi.dims[k] > 0 && vi.dims[k] != got[k])
+                    fail("Got invalid dimensions for input: " + vi.name + " for the following indices index: " +
+                         std::to_string(k) + " Got: " + std::to_string(got[k]) + " Expected: " + std::to_string(vi.dims[k]));
+        }
+        int v = L.new_val(vi.name, got);
+        L.vals[v].is_input = true;
+        L.vals[v].input_nchw = (L.vals[v].h * L.vals[v].w > 1);
+    }
+
+    // ---- ONNX nodes -> logical nodes with shape inference ---------------------------------------
+    for (const auto& on : m.nodes) {
+        if (on.outputs.empty() || on.inputs.empty()) fail("node " + on.name + " (" + on.op + ") has no inputs/outputs");
+        LNode n;
+        n.name = on.name.empty() ? on.outputs[0] : on.name;
+        const std::string& op = on.op;
+        auto in_val = [&](size_t k) { return L.get_val(on.inputs[k]); };
+        auto act_input = [&](size_t k) { return k < on.inputs.size() && !on.inputs[k].empty() && !L.init(on.inputs[k]); };
+        std::vector<int64_t> odims;
+
+        if (op == "Conv") {
+            if (!act_input(0)) fail("Conv " + n.name + ": constant input is not supported");
+            const OnnxTensor* w = L.init(on.inputs.at(1));
+            if (!w || w->dims.size() != 4) fail("Conv " + n.name + ": weights must be a 4-D initializer");
+            if (on.attr_i("group", 1) != 1) fail("Conv " + n.name + ": group != 1 is not supported");
+            int x = in_val(0);
+            const Val& X = L.vals[x];
+            if (X.dims.size() != 4) fail("Conv " + n.name + ": input must be 4-D");
+            int64_t co = w->dims[0], ci = w->dims[1];
+            if (ci != X.c) fail("Conv " + n.name + ": input channels " + std::to_string(X.c) + " != weight channels " + std::to_string(ci));
+            n.kind = L_CONV;
+            read_window_attrs(on, n, X.h, X.w, true, w);
+            if (n.kh != w->dims[2] || n.kw != w->dims[3]) fail("Conv " + n.name + ": kernel_shape does not match weights");
+            n.w.resize(size_t(co * ci * n.kh * n.kw));
+            for (int64_t o = 0; o < co; ++o)
+                for (int64_t c = 0; c < ci; ++c)
+                    for (int ky = 0; ky < n.kh; ++ky)
+                        for (int kx = 0; kx < n.kw; ++kx)
+                            n.w[size_t(((o * n.kh + ky) * n.kw + kx) * ci + c)] =
+                                w->f[size_t(((o * ci + c) * n.kh + ky) * n.kw + kx)];
+            if (on.inputs.size() > 2 && !on.inputs[2].empty()) {
+                const OnnxTensor* b = L.init(on.inputs[2]);
+                if (!b || b->numel() != co) fail("Conv " + n.name + ": bias must be a [Cout] initializer");
+                n.bias = b->f;
+            }
+            int64_t oh, ow;
+            conv_out_hw(X.h, X.w, n, false, oh, ow);
+            n.in = {x};
+            odims = {X.n, co, oh, ow};
+        } else if (op == "MatMul" || op == "Gemm") {
+            if (!act_input(0)) fail(op + " " + n.name + ": constant first operand is not supported");
+            const OnnxTensor* b = L.init(on.inputs.at(1));
+            if (!b || b->dims.size() != 2) fail(op + " " + n.name + ": second operand must be a 2-D initializer");
+            int x = in_val(0);
+            const Val& X = L.vals[x];
+            if (X.h * X.w != 1) fail(op + " " + n.name + ": input must be [N, K]");
+            bool transB = op == "Gemm" && on.attr_i("transB", 0) != 0;
+            if (op == "Gemm" && on.attr_i("transA", 0) != 0) fail("Gemm " + n.name + ": transA is not supported");
+            float alpha = op == "Gemm" ? on.attr_f("alpha", 1.f) : 1.f;
+            float beta = op == "Gemm" ? on.attr_f("beta", 1.f) : 1.f;
+            int64_t K = transB ? b->dims[1] : b->dims[0], N = transB ? b->dims[0] : b->dims[1];
+            if (K != X.c) fail(op + " " + n.name + ": inner dimensions do not match");
+            n.kind = L_CONV;
+            n.w.resize(size_t(N * K));
+            for (int64_t o = 0; o < N; ++o)
+                for (int64_t k = 0; k < K; ++k)
+                    n.w[size_t(o * K + k)] = alpha * (transB ? b->f[size_t(o * K + k)] : b->f[size_t(k * N + o)]);
+            if (op == "Gemm" && on.inputs.size() > 2 && !on.inputs[2].empty()) {
+                const OnnxTensor* c = L.init(on.inputs[2]);
+                if (!c) fail("Gemm " + n.name + ": C must be an initializer");
+                if (c->numel() == N) n.bias = c->f;
+                else if (c->numel() == 1) n.bias.assign(size_t(N), c->f[0]);
+                else fail("Gemm " + n.name + ": C must broadcast over rows");
+                for (auto& v : n.bias) v *= beta;
+            }
+            n.in = {x};
+            odims = {X.n, N};
+            if (X.dims.size() == 1) odims = {N};
+        } else if (op == "BatchNormalization") {
+            int x = in_val(0);
+            const Val& X = L.vals[x];
+            const OnnxTensor *g = L.init(on.inputs.at(1)), *be = L.init(on.inputs.at(2)), *mu = L.init(on.inputs.at(3)),
+                             *var = L.init(on.inputs.at(4));
+            if (!g || !be || !mu || !var) fail("BatchNormalization " + n.name + ": parameters must be initializers");
+            if (g->numel() != X.c || be->numel() != X.c || mu->numel() != X.c || var->numel() != X.c)
+                fail("BatchNormalization " + n.name + ": parameter size != channels");
+            double eps = on.attr_f("epsilon", 1e-5f);
+            n.kind = L_AFFINE;
+            n.s.resize(size_t(X.c)); n.t.resize(size_t(X.c));
+            for (int64_t c = 0; c < X.c; ++c) {
+                double s = double(g->f[c]) / std::sqrt(double(var->f[c]) + eps);
+                n.s[c] = float(s);
+                n.t[c] = float(double(be->f[c]) - double(mu->f[c]) * s);
+            }
+            n.in = {x};
+            odims = X.dims;
+        } else if (op == "Relu") {
+            n.kind = L_RELU;
+            n.in = {in_val(0)};
+            odims = L.vals[n.in[0]].dims;
+        } else if (op == "Add" || op == "Mul") {
+            bool a0 = act_input(0), a1 = act_input(1);
+            if (a0 && a1) {
+                if (op == "Mul") fail("Mul of two activations is not supported (node " + n.name + ")");
+                int a = in_val(0), b = in_val(1);
+                if (L.vals[a].dims != L.vals[b].dims) fail("Add " + n.name + ": broadcasting between activations is not supported");
+                n.kind = L_ADD;
+                n.in = {a, b};
+                odims = L.vals[a].dims;
+            } else if (a0 || a1) {
+                int x = in_val(a0 ? 0 : 1);
+                const OnnxTensor* c = L.init(on.inputs[a0 ? 1 : 0]);
+                std::vector<float> pc;
+                // rank-1 constant against a rank-2 activation aligns with the last (= channel) axis
+                const Val& X = L.vals[x];
+                bool ok = L.per_channel_const(*c, X, pc);
+                if (!ok && X.dims.size() == 2 && c->dims.size() == 1 && c->numel() == X.c) { pc = c->f; ok = true; }
+                if (!ok && X.dims.size() == 2 && c->dims.size() == 2 && c->dims[0] == 1 && c->dims[1] == X.c) { pc = c->f; ok = true; }
+                if (!ok) fail(op + " " + n.name + ": constant operand must broadcast per channel");
+                n.kind = L_AFFINE;
+                if (op == "Add") { n.s.assign(size_t(X.c), 1.f); n.t = pc; }
+                else { n.s = pc; n.t.assign(size_t(X.c), 0.f); }
+                n.in = {x};
+                odims = X.dims;
+            } else fail(op + " " + n.name + ": constant folding of two initializers is not supported");
+        } else if (op == "Concat") {
+            int64_t axis = on.attr_i("axis", 1);
+            n.kind = L_CONCAT;
+            for (size_t k = 0; k < on.inputs.size(); ++k) {
+                if (!act_input(k)) fail("Concat " + n.name + ": constant inputs are not supported");
+                n.in.push_back(in_val(k));
+            }
+            const Val& X0 = L.vals[n.in[0]];
+            if (axis < 0) axis += int64_t(X0.dims.size());
+            if (axis != 1) fail("Concat " + n.name + ": only axis=1 (channels) is supported");
+            odims = X0.dims;
+            int64_t ctot = 0;
+            for (int v : n.in) {
+                const Val& X = L.vals[v];
+                if (X.dims.size() != X0.dims.size()) fail("Concat " + n.name + ": rank mismatch");
+                for (size_t k = 0; k < X.dims.size(); ++k)
+                    if (k != 1 && X.dims[k] != X0.dims[k]) fail("Concat " + n.name + ": shape mismatch");
+                ctot += X.c;
+            }
+            odims[1] = ctot;
+        } else if (op == "MaxPool" || op == "AveragePool") {
+            int x = in_val(0);
+            const Val& X = L.vals[x];
+            if (X.dims.size() != 4) fail(op + " " + n.name + ": input must be 4-D");
+            if (on.outputs.size() > 1 && !on.outputs[1].empty()) fail("MaxPool " + n.name + ": Indices output is not supported");
+            n.kind = op == "MaxPool" ? L_MAXPOOL : L_AVGPOOL;
+            read_window_attrs(on, n, X.h, X.w, false, nullptr);
+            n.count_include_pad = on.attr_i("count_include_pad", 0) != 0;
+            int64_t oh, ow;
+            conv_out_hw(X.h, X.w, n, on.attr_i("ceil_mode", 0) != 0, oh, ow);
+            n.in = {x};
+            odims = {X.n, X.c, oh, ow};
+        } else if (op == "GlobalAveragePool") {
+            int x = in_val(0);
+            const Val& X = L.vals[x];
+            if (X.dims.size() != 4) fail("GlobalAveragePool " + n.name + ": input must be 4-D");
+            n.kind = L_GAP;
+            n.in = {x};
+            odims = {X.n, X.c, 1, 1};
+        } else if (op == "Flatten" || op == "Reshape" || op == "Identity" || op == "Dropout" || op == "Squeeze") {
+            int x = in_val(0);
+            const Val& X = L.vals[x];
+            n.kind = L_ALIAS;
+            n.in = {x};
+            if (op == "Identity" || op == "Dropout") odims = X.dims;
+            else {
+                // Storage is NHWC: a reshape is a pure alias only when H*W == 1 on both sides.
+                if (X.h * X.w != 1) fail(op + " " + n.name + ": only supported on [N,C,1,1] / [N,C] tensors");
+                if (op == "Flatten") {
+                    if (on.attr_i("axis", 1) != 1) fail("Flatten " + n.name + ": only axis=1 is supported");
+                    odims = {X.n, X.c};
+                } else if (op == "Squeeze") odims = {X.n, X.c};
+                else {
+                    const OnnxTensor* shp = on.inputs.size() > 1 ? L.init(on.inputs[1]) : nullptr;
+                    if (!shp) fail("Reshape " + n.name + ": shape must be an initializer");
+                    std::vector<int64_t> d = shp->i;
+                    int64_t known = 1, neg = -1;
+                    for (size_t k = 0; k < d.size(); ++k) {
+                        if (d[k] == 0 && k < X.dims.size()) d[k] = X.dims[k];
+                        if (d[k] == -1) neg = int64_t(k); else known *= d[k];
+                    }
+                    if (neg >= 0) d[size_t(neg)] = X.n * X.c / known;
+                    int64_t tot = 1; for (auto v : d) tot *= v;
+                    if (tot != X.n * X.c || d.empty() || d[0] != X.n) fail("Reshape " + n.name + ": must keep the batch axis");
+                    for (size_t k = 2; k < d.size(); ++k) if (d[k] != 1) fail("Reshape " + n.name + ": unsupported target shape");
+                    odims = d;
+                }
+            }
+        } else {
+            fail("Unsupported ONNX operator: " + op + " (node " + n.name + ")");
+        }
+        n.out = L.new_val(on.outputs[0], odims);
+        L.vals[n.out].producer = int(L.nodes.size());
+        L.nodes.push_back(std::move(n));
+    }
+
+    for (const auto& vo : m.outputs) {
+        int v = L.get_val(vo.name);
+        L.vals[v].is_output = true;
+    }
+
+    auto single_consumer = [&](int v) { return !L.vals[v].is_output && L.consumers(v).size() == 1; };
+
+    // ---- fusion 1: merge Affine->Affine chains (BN followed by Caffe-style Scale Mul/Add) ----------
+    for (size_t i = 0; i < L.nodes.size(); ++i) {
+        LNode& a = L.nodes[i];
+        if (a.dead || a.kind != L_AFFINE) continue;
+        while (single_consumer(a.out)) {
+            int ci = L.consumers(a.out)[0];
+            LNode& b = L.nodes[ci];
+            if (b.kind != L_AFFINE) break;
+            for (size_t c = 0; c < a.s.size(); ++c) {
+                a.t[c] = b.s[c] * a.t[c] + b.t[c];
+                a.s[c] = b.s[c] * a.s[c];
+            }
+            a.name += "+" + b.name;
+            a.out = b.out;
+            L.vals[a.out].producer = int(i);
+            b.dead = true;
+        }
+    }
+    // ---- fusion 2: conv epilogues (Conv -> Affine -> Relu) -----------------------------------------
+    for (size_t i = 0; i < L.nodes.size(); ++i) {
+        LNode& cv = L.nodes[i];
+        if (cv.dead || cv.kind != L_CONV) continue;
+        int64_t cout = L.vals[cv.out].c;
+        size_t kper = cv.w.size() / size_t(cout);
+        while (single_consumer(cv.out) && !cv.relu) {
+            int ci = L.consumers(cv.out)[0];
+            LNode& b = L.nodes[ci];
+            if (b.kind == L_AFFINE) {
+                if (cv.bias.empty()) cv.bias.assign(size_t(cout), 0.f);
+                for (int64_t o = 0; o < cout; ++o) {
+                    for (size_t k = 0; k < kper; ++k) cv.w[size_t(o) * kper + k] *= b.s[o];
+                    cv.bias[o] = cv.bias[o] * b.s[o] + b.t[o];
+                }
+            } else if (b.kind == L_RELU) cv.relu = true;
+            else break;
+            cv.name += "+" + b.name;
+            cv.out = b.out;
+            L.vals[cv.out].producer = int(i);
+            b.dead = true;
+        }
+    }
+    // ---- fusion 3: prologues (Affine -> Relu -> {Conv, GlobalAveragePool}) -------------------------
+    for (size_t i = 0; i < L.nodes.size(); ++i) {
+        LNode& cv = L.nodes[i];
+        if (cv.dead || (cv.kind != L_CONV && cv.kind != L_GAP)) continue;
+        int x = cv.in[0];
+        bool took_relu = false;
+        int p = L.vals[x].producer;
+        if (p >= 0 && !L.nodes[p].dead && L.nodes[p].kind == L_RELU && single_consumer(x)) {
+            cv.pre_relu = true;
+            cv.has_pre = true;
+            cv.name = L.nodes[p].name + "+" + cv.name;
+            L.nodes[p].dead = true;
+            x = L.nodes[p].in[0];
+            took_relu = true;
+        }
+        p = L.vals[x].producer;
+        if (p >= 0 && !L.nodes[p].dead && L.nodes[p].kind == L_AFFINE && !L.vals[x].is_output) {
+            // live consumers of x: none if its Relu was just absorbed, else exactly this node
+            std::vector<int> cons = L.consumers(x);
+            bool ok = took_relu ? cons.empty() : (cons.size() == 1 && cons[0] == int(i));
+            if (ok) {
+                cv.pre_s = L.nodes[p].s;
+                cv.pre_t = L.nodes[p].t;
+                cv.has_pre = true;
+                cv.name = L.nodes[p].name + "+" + cv.name;
+                L.nodes[p].dead = true;
+                x = L.nodes[p].in[0];
+            }
+        }
+        if (cv.has_pre && cv.pre_s.empty()) {
+            cv.pre_s.assign(size_t(L.vals[x].c), 1.f);
+            cv.pre_t.assign(size_t(L.vals[x].c), 0.f);
+        }
+        cv.in[0] = x;
+    }
+    // ---- fusion 4: Add -> Relu, Affine -> Relu -----------------------------------------------------
+    for (size_t i = 0; i < L.nodes.size(); ++i) {
+        LNode& a = L.nodes[i];
+        if (a.dead || (a.kind != L_ADD && a.kind != L_AFFINE)) continue;
+        if (single_consumer(a.out)) {
+            LNode& b = L.nodes[L.consumers(a.out)[0]];
+            if (b.kind == L_RELU) {
+                a.relu = true;
+                a.name += "+" + b.name;
+                a.out = b.out;
+                L.vals[a.out].producer = int(i);
+                b.dead = true;
+            }
+        }
+    }
+
+    // ---- graph inputs in NCHW: only convs can read them strided; otherwise stage an NHWC copy ------
+    {
+        std::vector<LNode> pre;
+        for (size_t v = 0; v < L.vals.size(); ++v) {
+            if (!L.vals[v].is_input || !L.vals[v].input_nchw) continue;
+            bool all_conv = true;
+            for (int ci : L.consumers(int(v))) if (L.nodes[ci].kind != L_CONV) all_conv = false;
+            if (all_conv && !L.vals[v].is_output) continue;
+            LNode cp;
+            cp.kind = L_COPY;
+            cp.name = "nchw_to_nhwc(" + L.vals[v].name + ")";
+            cp.in = {int(v)};
+            cp.out = L.new_val(L.vals[v].name + "/nhwc", L.vals[v].dims);
+            for (auto& nd : L.nodes) if (!nd.dead) for (int& x : nd.in) if (x == int(v)) x = cp.out;
+            pre.push_back(cp);
+        }
+        if (!pre.empty()) {
+            size_t shift = pre.size();
+            L.nodes.insert(L.nodes.begin(), pre.begin(), pre.end());
+            for (auto& val : L.vals) if (val.producer >= 0) val.producer += int(shift);
+            for (size_t k = 0; k < shift; ++k) L.vals[L.nodes[k].out].producer = int(k);
+        }
+    }
+
+    // ---- graph outputs must end up dense (NCHW order) in their own buffer --------------------------
+    std::vector<int> out_vals;
+    for (const auto& vo : m.outputs) {
+        int v = L.get_val(vo.name);
+        // Always materialise through a copy when the tensor is spatial (NHWC->NCHW) or is a graph input;
+        // [N,C,1,1] / [N,C] tensors are already in ABI order and only need their own dense buffer.
+        bool spatial = L.vals[v].h * L.vals[v].w > 1;
+        bool consumed = !L.consumers(v).empty();
+        if (spatial || L.vals[v].is_input || consumed) {
+            LNode cp;
+            cp.kind = L_COPY;
+            cp.name = "to_output(" + L.vals[v].name + ")";
+            cp.in = {v};
+            cp.out = L.new_val(L.vals[v].name + "/out", L.vals[v].dims);
+            L.vals[cp.out].is_output = true;
+            L.vals[cp.out].input_nchw = spatial;   // reused flag: dense NCHW layout
+            L.vals[v].is_output = false;
+            L.vals[cp.out].producer = int(L.nodes.size());
+            L.nodes.push_back(cp);
+            out_vals.push_back(cp.out);
+        } else out_vals.push_back(v);
+    }
+
+    // ---- concat / alias placement ---------------------------------------------------------------
+    for (int i = int(L.nodes.size()) - 1; i >= 0; --i) {
+        LNode& n = L.nodes[i];
+        if (n.dead) continue;
+        if (n.kind == L_ALIAS) {
+            Val& src = L.vals[n.in[0]];
+            // the alias output shares storage with its input: make the *input* a child of the output
+            if (src.parent < 0 && !src.is_input && !src.is_output) { src.parent = n.out; src.parent_off = 0; }
+            else {  // cannot alias: degrade to a copy
+                n.kind = L_COPY;
+            }
+        } else if (n.kind == L_CONCAT) {
+            int64_t off = 0;
+            for (size_t k = 0; k < n.in.size(); ++k) {
+                Val& src = L.vals[n.in[k]];
+                bool dup = false;
+                for (size_t j = 0; j < k; ++j) if (n.in[j] == n.in[k]) dup = true;
+                if (src.parent < 0 && !src.is_input && !src.is_output && !dup) { src.parent = n.out; src.parent_off = off; }
+                off += src.c;
+            }
+        }
+    }
+    // roots, absolute offsets
+    std::vector<int64_t> pitch(L.vals.size(), 0);
+    for (size_t v = 0; v < L.vals.size(); ++v) {
+        int r = int(v);
+        int64_t off = 0;
+        while (L.vals[r].parent >= 0) { off += L.vals[r].parent_off; r = L.vals[r].parent; }
+        L.vals[v].root = r;
+        L.vals[v].abs_off = off;
+    }
+
+    // ---- liveness over live nodes, buffer recycling -------------------------------------------------
+    std::vector<int> order;
+    for (size_t i = 0; i < L.nodes.size(); ++i) if (!L.nodes[i].dead) order.push_back(int(i));
+    const int INF = 1 << 30;
+    std::vector<int> first_def(L.vals.size(), INF), last_use(L.vals.size(), -1);
+    std::vector<char> used(L.vals.size(), 0);
+    for (size_t v = 0; v < L.vals.size(); ++v)
+        if (L.vals[v].is_input) { first_def[L.vals[v].root] = -1; used[L.vals[v].root] = 1; }
+    for (size_t pos = 0; pos < order.size(); ++pos) {
+        const LNode& n = L.nodes[order[pos]];
+        int r = L.vals[n.out].root;
+        used[r] = 1;
+        first_def[r] = std::min(first_def[r], int(pos));
+        last_use[r] = std::max(last_use[r], int(pos));
+        for (int x : n.in) { int rx = L.vals[x].root; last_use[rx] = std::max(last_use[rx], int(pos)); used[rx] = 1; }
+    }
+    for (int v : out_vals) last_use[L.vals[v].root] = INF;
+    for (size_t v = 0; v < L.vals.size(); ++v) if (L.vals[v].is_input) last_use[L.vals[v].root] = INF;  // staging buffers stay dedicated
+
+    auto root_floats = [&](int r) {
+        const Val& R = L.vals[r];
+        return R.n * R.c * R.h * R.w;
+    };
+    std::multimap<int64_t, int> free_pool;   // size -> buffer id
+    auto alloc_buf = [&](int r) {
+        int64_t need = root_floats(r);
+        bool dedicated = last_use[r] == INF;
+        if (!dedicated) {
+            auto it = free_pool.lower_bound(need);
+            // accept a recycled buffer up to 2x the needed size; otherwise grow a new one
+            if (it != free_pool.end() && it->first <= 2 * need) {
+                int b = it->second;
+                free_pool.erase(it);
+                L.vals[r].buf = b;
+                return;
+            }
+        }
+        plan.buffer_floats.push_back(need);
+        L.vals[r].buf = int(plan.buffer_floats.size()) - 1;
+    };
+    for (size_t v = 0; v < L.vals.size(); ++v)
+        if (used[v] && L.vals[v].root == int(v) && first_def[v] == -1) alloc_buf(int(v));
+    for (size_t pos = 0; pos < order.size(); ++pos) {
+        for (size_t v = 0; v < L.vals.size(); ++v)
+            if (used[v] && L.vals[v].root == int(v) && first_def[v] == int(pos)) alloc_buf(int(v));
+        for (size_t v = 0; v < L.vals.size(); ++v)
+            if (used[v] && L.vals[v].root == int(v) && last_use[v] == int(pos) && L.vals[v].buf >= 0)
+                free_pool.insert({plan.buffer_floats[size_t(L.vals[v].buf)], L.vals[v].buf});
+    }
+
+    auto view_of = [&](int v) {
+        const Val& X = L.vals[v];
+        const Val& R = L.vals[X.root];
+        View w;
+        w.buf = R.buf;
+        w.n = X.n; w.c = X.c; w.h = X.h; w.w = X.w;
+        w.c_off = X.abs_off;
+        w.pitch = R.c;
+        w.nchw = (X.is_input || X.is_output) && X.input_nchw;
+        if (w.buf < 0) fail("internal planner error: value " + X.name + " has no buffer");
+        return w;
+    };
+
+    // ---- emit steps --------------------------------------------------------------------------------
+    auto push_vec = [&](const std::vector<float>& v) {
+        while (plan.weights.size() % 4) plan.weights.push_back(0.f);
+        int64_t off = int64_t(plan.weights.size());
+        plan.weights.insert(plan.weights.end(), v.begin(), v.end());
+        return off;
+    };
+    for (int idx : order) {
+        const LNode& n = L.nodes[idx];
+        if (n.kind == L_ALIAS) continue;
+        Step s;
+        s.name = n.name;
+        if (n.kind == L_CONCAT) {
+            // members that could not be placed in the parent buffer are copied into their slice
+            int64_t off = 0;
+            for (size_t k = 0; k < n.in.size(); ++k) {
+                const Val& src = L.vals[n.in[k]];
+                bool placed = src.root == L.vals[n.out].root && src.abs_off == L.vals[n.out].abs_off + off;
+                if (!placed) {
+                    Step c;
+                    c.kind = StepKind::Copy;
+                    c.name = n.name + "/copy" + std::to_string(k);
+                    c.in = view_of(n.in[k]);
+                    c.out = view_of(n.out);
+                    c.out.c = src.c;
+                    c.out.c_off += off;
+                    c.bytes = 8.0 * double(c.in.numel());
+                    plan.steps.push_back(c);
+                }
+                off += src.c;
+            }
+            continue;
+        }
+        s.in = view_of(n.in[0]);
+        s.out = view_of(n.out);
+        s.relu = n.relu;
+        if (n.has_pre) {
+            s.pre_scale_off = push_vec(n.pre_s);
+            s.pre_shift_off = push_vec(n.pre_t);
+            s.pre_relu = n.pre_relu;
+        }
+        switch (n.kind) {
+            case L_CONV: {
+                s.kind = StepKind::Conv;
+                s.kh = n.kh; s.kw = n.kw; s.sh = n.sh; s.sw = n.sw; s.pt = n.pt; s.pl = n.pl; s.pb = n.pb; s.pr = n.pr;
+                s.w_off = push_vec(n.w);
+                if (!n.bias.empty()) s.bias_off = push_vec(n.bias);
+                int64_t M = s.out.n * s.out.h * s.out.w, N = s.out.c, K = int64_t(n.kh) * n.kw * s.in.c;
+                s.flops = 2.0 * double(M) * double(N) * double(K);
+                s.bytes = 4.0 * (double(s.in.numel()) + double(s.out.numel()) + double(n.w.size()));
+                bool vec_ok = !s.in.nchw && s.in.c % 4 == 0 && s.in.pitch % 4 == 0 && s.in.c_off % 4 == 0;
+                if (M * N < 2048 && K <= 4096) s.algo = ConvAlgo::Naive;
+                else if (vec_ok) s.algo = ConvAlgo::IgemmVec;
+                else if (K <= 2048) s.algo = ConvAlgo::IgemmScalar;
+                else s.algo = ConvAlgo::Naive;
+                s.tile = choose_tile(M, N);
+                // Test / tuning overrides (read at plan time): IE_FORCE_TILE=<0..6>, IE_FORCE_ALGO=naive|scalar
+                if (const char* ft = std::getenv("IE_FORCE_TILE")) {
+                    int t = std::atoi(ft);
+                    if (t >= 0 && t < kNumIgemmTiles) s.tile = t;
+                }
+                if (const char* fa = std::getenv("IE_FORCE_ALGO")) {
+                    std::string f = fa;
+                    if (f == "naive") s.algo = ConvAlgo::Naive;
+                    else if (f == "scalar" && K <= 2048) s.algo = ConvAlgo::IgemmScalar;
+                    else if (f == "igemm" && s.algo == ConvAlgo::Naive) s.algo = vec_ok ? ConvAlgo::IgemmVec : (K <= 2048 ? ConvAlgo::IgemmScalar : ConvAlgo::Naive);
+                }
+                break;
+            }
+            case L_MAXPOOL: case L_AVGPOOL:
+                s.kind = StepKind::Pool;
+                s.pool_max = n.kind == L_MAXPOOL;
+                s.count_include_pad = n.count_include_pad;
+                s.kh = n.kh; s.kw = n.kw; s.sh = n.sh; s.sw = n.sw; s.pt = n.pt; s.pl = n.pl; s.pb = n.pb; s.pr = n.pr;
+                s.bytes = 4.0 * (double(s.in.numel()) + double(s.out.numel()));
+                s.flops = double(s.out.numel()) * n.kh * n.kw;
+                break;
+            case L_GAP:
+                s.kind = StepKind::GlobalAvgPool;
+                s.bytes = 4.0 * (double(s.in.numel()) + double(s.out.numel()));
+                s.flops = double(s.in.numel());
+                break;
+            case L_AFFINE:
+                s.kind = StepKind::Eltwise;
+                s.pre_scale_off = push_vec(n.s);
+                s.pre_shift_off = push_vec(n.t);
+                s.bytes = 8.0 * double(s.in.numel());
+                s.flops = 2.0 * double(s.in.numel());
+                break;
+            case L_RELU:
+                s.kind = StepKind::Eltwise;
+                s.relu = true;
+                s.bytes = 8.0 * double(s.in.numel());
+                break;
+            case L_ADD:
+                s.kind = StepKind::Eltwise;
+                s.in2 = view_of(n.in[1]);
+                s.has_in2 = true;
+                s.bytes = 12.0 * double(s.in.numel());
+                s.flops = double(s.in.numel());
+                break;
+            case L_COPY:
+                s.kind = StepKind::Copy;
+                s.bytes = 8.0 * double(s.in.numel());
+                break;
+            default: fail("internal planner error: unexpected node kind");
+        }
+        if (s.kind != StepKind::Conv && s.kind != StepKind::Copy && s.in.nchw)
+            fail("internal planner error: NCHW view reached a non-conv step");
+        plan.total_flops += s.flops;
+        plan.total_bytes += s.bytes;
+        plan.steps.push_back(std::move(s));
+    }
+    while (plan.weights.size() % 4) plan.weights.push_back(0.f);
+
+    // ---- I/O descriptors ---------------------------------------------------------------------------
+    for (size_t i = 0; i < m.inputs.size(); ++i) {
+        IoDesc d;
+        d.name = m.inputs[i].name;
+        d.elem_type = m.inputs[i].elem_type;
+        d.model_dims = m.inputs[i].dims;
+        d.dims = input_shapes[i];
+        int v = L.get_val(d.name);
+        if (!used[size_t(L.vals[v].root)]) {   // input never consumed: still give it a staging buffer
+            plan.buffer_floats.push_back(root_floats(v));
+            L.vals[v].buf = int(plan.buffer_floats.size()) - 1;
+        }
+        d.view = view_of(v);
+        plan.inputs.push_back(d);
+    }
+    for (size_t i = 0; i < m.outputs.size(); ++i) {
+        IoDesc d;
+        d.name = m.outputs[i].name;
+        d.elem_type = m.outputs[i].elem_type;
+        d.model_dims = m.outputs[i].dims;
+        d.dims = L.vals[out_vals[i]].dims;
+        d.view = view_of(out_vals[i]);
+        if (!d.view.nchw && (d.view.c_off != 0 || d.view.pitch != d.view.c || d.view.h * d.view.w != 1))
+            fail("internal planner error: output " + d.name + " is not dense");
+        plan.outputs.push_back(d);
+    }
+    return plan;
+}
+
+static void json_view(std::ostringstream& o, const View& v) {
+    o << "{\"buf\":" << v.buf << ",\"n\":" << v.n << ",\"c\":" << v.c << ",\"h\":" << v.h << ",\"w\":" << v.w
+      << ",\"c_off\":" << v.c_off << ",\"pitch\":" << v.pitch << ",\"nchw\":" << (v.nchw ? "true" : "false") << "}";
+}
+static std::string json_escape(const std::string& s) {
+    std::string o;
+    for (char c : s) { if (c == '"' || c == '\\') o += '\\'; if (uint8_t(c) >= 0x20) o += c; }
+    return o;
+}
+
+std::string PlanToJson(const Plan& p) {
+    static const char* kinds[] = {"conv", "pool", "gap", "eltwise", "copy"};
+    static const char* algos[] = {"igemm_vec", "igemm_scalar", "naive"};
+    std::ostringstream o;
+    o.precision(17);
+    o << "{\"inputs\":[";
+    for (size_t i = 0; i < p.inputs.size(); ++i) {
+        o << (i ? "," : "") << "{\"name\":\"" << json_escape(p.inputs[i].name) << "\",\"dims\":[";
+        for (size_t k = 0; k < p.inputs[i].dims.size(); ++k) o << (k ? "," : "") << p.inputs[i].dims[k];
+        o << "],\"view\":"; json_view(o, p.inputs[i].view); o << "}";
+    }
+    o << "],\"outputs\":[";
+    for (size_t i = 0; i < p.outputs.size(); ++i) {
+        o << (i ? "," : "") << "{\"name\":\"" << json_escape(p.outputs[i].name) << "\",\"dims\":[";
+        for (size_t k = 0; k < p.outputs[i].dims.size(); ++k) o << (k ? "," : "") << p.outputs[i].dims[k];
+        o << "],\"view\":"; json_view(o, p.outputs[i].view); o << "}";
+    }
+    o << "],\"buffers\":[";
+    for (size_t i = 0; i < p.buffer_floats.size(); ++i) o << (i ? "," : "") << p.buffer_floats[i];
+    o << "],\"weight_floats\":" << p.weights.size() << ",\"total_flops\":" << p.total_flops
+      << ",\"total_bytes\":" << p.total_bytes << ",\"steps\":[";
+    for (size_t i = 0; i < p.steps.size(); ++i) {
+        const Step& s = p.steps[i];
+        o << (i ? "," : "") << "{\"kind\":\"" << kinds[int(s.kind)] << "\",\"name\":\"" << json_escape(s.name) << "\",\"in\":";
+        json_view(o, s.in);
+        if (s.has_in2) { o << ",\"in2\":"; json_view(o, s.in2); }
+        o << ",\"out\":"; json_view(o, s.out);
+        o << ",\"k\":[" << s.kh << "," << s.kw << "],\"stride\":[" << s.sh << "," << s.sw << "],\"pads\":[" << s.pt << ","
+          << s.pl << "," << s.pb << "," << s.pr << "]";
+        o << ",\"pre\":" << (s.pre_scale_off >= 0 ? "true" : "false") << ",\"pre_relu\":" << (s.pre_relu ? "true" : "false")
+          << ",\"relu\":" << (s.relu ? "true" : "false") << ",\"bias\":" << (s.bias_off >= 0 ? "true" : "false");
+        if (s.kind == StepKind::Conv) o << ",\"algo\":\"" << algos[int(s.algo)] << "\",\"tile\":" << s.tile;
+        if (s.kind == StepKind::Pool) o << ",\"max\":" << (s.pool_max ? "true" : "false");
+        o << ",\"flops\":" << s.flops << ",\"bytes\":" << s.bytes << "}";
+    }
+    o << "]}";
+    return o.str();
+}
+
+}  // namespace ie

@@ -1,0 +1,91 @@
+// Graph planner: ONNX graph -> fused NHWC execution plan (host-only code, no HIP).
+//
+// This is the part of `Ort::Session` construction the reference relies on at model.cpp:843-847
+// (parse + ORT_ENABLE_ALL graph optimisation, model.cpp:896) re-designed for MI355X:
+//   * activations live in NHWC buffers (channels contiguous -> coalesced 16 B/lane HBM access)
+//   * BatchNormalization is folded to per-channel scale/shift at load and fused either into the
+//     producing conv's weights/bias (Conv->BN->ReLU) or into the consuming conv's operand staging
+//     (DenseNet's pre-activation BN->ReLU->Conv)
+//   * Concat(axis=1) is free: producers write into channel slices of one planned buffer
+//   * dead activation buffers are recycled so the working set stays inside the 256 MiB Infinity Cache
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "onnx_reader.h"
+
+namespace ie {
+
+// An activation tensor inside a device buffer.  NHWC unless `nchw` (graph inputs/outputs as the ABI hands them).
+struct View {
+    int buf = -1;
+    int64_t n = 0, c = 0, h = 1, w = 1;
+    int64_t c_off = 0;    // first channel inside the buffer's pixel row
+    int64_t pitch = 0;    // floats per pixel row of the buffer (>= c_off + c)
+    bool nchw = false;    // dense NCHW (pitch/c_off unused)
+    int64_t numel() const { return n * c * h * w; }
+};
+
+enum class StepKind : int { Conv = 0, Pool = 1, GlobalAvgPool = 2, Eltwise = 3, Copy = 4 };
+
+// Conv algorithm chosen at plan time.
+enum class ConvAlgo : int {
+    IgemmVec = 0,     // MFMA implicit GEMM, NHWC float4 operand staging (Cin % 4 == 0)
+    IgemmScalar = 1,  // MFMA implicit GEMM, scalar gather staging (any Cin / NCHW input, e.g. the 7x7 stem)
+    Naive = 2         // one thread per output element (tiny or odd shapes, and on-device cross-check)
+};
+
+struct Step {
+    StepKind kind = StepKind::Conv;
+    std::string name;          // ONNX node name(s) this step came from (profiling / debugging)
+    View in, in2, out;         // in2: second operand of a residual Add
+    bool has_in2 = false;
+    // conv / pool geometry
+    int kh = 1, kw = 1, sh = 1, sw = 1, pt = 0, pl = 0, pb = 0, pr = 0;
+    bool pool_max = false;
+    bool count_include_pad = false;
+    // offsets (in floats) into the weight blob; -1 = absent
+    int64_t w_off = -1;        // conv weights packed [Cout][kh][kw][Cin]
+    int64_t bias_off = -1;     // [Cout]
+    int64_t pre_scale_off = -1, pre_shift_off = -1;   // per input channel, applied before the op (then pre_relu)
+    bool pre_relu = false;
+    bool relu = false;         // applied to the result
+    ConvAlgo algo = ConvAlgo::Naive;
+    int tile = 0;              // igemm tile configuration index (see kernels.h)
+    double flops = 0;          // algorithmic FLOPs (2*MACs) of this step for the planned shape
+    double bytes = 0;          // algorithmic bytes: operands read once + result written once
+};
+
+struct IoDesc {
+    std::string name;
+    int elem_type = ONNX_FLOAT;
+    std::vector<int64_t> model_dims;   // as declared in the ONNX file (-1 = symbolic)
+    std::vector<int64_t> dims;         // resolved for this plan
+    View view;                         // device staging view (dense NCHW order as the ABI expects)
+};
+
+struct Plan {
+    std::vector<IoDesc> inputs, outputs;
+    std::vector<int64_t> buffer_floats;   // size of each device activation buffer
+    std::vector<Step> steps;
+    std::vector<float> weights;           // packed blob (batch independent)
+    double total_flops = 0, total_bytes = 0;
+    int64_t activation_floats() const { int64_t s = 0; for (auto b : buffer_floats) s += b; return s; }
+};
+
+// Static (shape independent) facts, available right after parsing: what ExtractModelMetadata
+// (model.cpp:910-972) and EstimateModelMemoryUsage (model.cpp:979-1035) report.
+struct ModelInfo {
+    std::vector<OnnxValueInfo> inputs, outputs;
+    size_t memory_usage_bytes = 0;
+};
+ModelInfo DescribeModel(const OnnxModel& m);
+
+// Build the plan for concrete input shapes (one entry per graph input, in graph order).
+// Throws std::runtime_error with an ORT-like message on unsupported ops or shape mismatches.
+Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& input_shapes);
+
+std::string PlanToJson(const Plan& p);
+
+}  // namespace ie

@@ -1,0 +1,44 @@
+/*
+ * Extensions of the MI355X engine beyond the reference ABI (nothing here is needed by the Go binding).
+ * They exist for (a) device-resident benchmarking — the reference's ModelInfer (inference_bridge.cpp:692-828)
+ * only takes host buffers, (b) per-kernel roofline measurement, (c) the RCCL weight broadcast that the
+ * one-process-per-GPU launcher performs with torch.distributed, (d) host-only graph inspection for CPU tests.
+ * Plain pointers and sizes only; strings are malloc'd and released with FreeErrorMessage().
+ */
+#ifndef INFERENCE_ENGINE_EXT_H
+#define INFERENCE_ENGINE_EXT_H
+
+#include "inference_bridge.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Host-only (no GPU needed): parse <path>/model.onnx (or a .onnx file) and return a JSON document with the graph's
+ * inputs/outputs, the reference's memory_usage_bytes estimate (model.cpp:979-1035) and, when batch > 0, the fused
+ * execution plan for that batch (symbolic leading dims are replaced by `batch`).  NULL + *error on failure. */
+char* EngineDescribeModel(const char* path, int batch, ErrorMessage* error);
+
+/* Plan + allocate + capture the hipGraph for these input shapes (one Shape per graph input, graph order) and return
+ * the engine-owned device buffers: d_inputs[i] is dense NCHW fp32 of input i, d_outputs[j] dense fp32 of output j. */
+bool EnginePrepare(ModelHandle handle, const Shape* input_shapes, int num_inputs, void** d_inputs, void** d_outputs,
+                   int num_outputs, ErrorMessage* error);
+/* Enqueue `iters` forwards of the last prepared plan on the model's stream using the data already in its device
+ * buffers; waits for completion when sync != 0. */
+bool EngineRunPrepared(ModelHandle handle, int iters, int sync, ErrorMessage* error);
+bool EngineSynchronize(ModelHandle handle, ErrorMessage* error);
+/* hipStream_t the model launches on (for HIP-event timing by the caller). */
+void* EngineGetStream(ModelHandle handle);
+/* Eager (non-graph) forwards of the prepared plan with HIP events around every kernel launch; JSON list of
+ * {name, kernel, ms, flops, bytes} per step (ms averaged over iters). */
+char* EngineProfile(ModelHandle handle, int iters, ErrorMessage* error);
+/* Packed fp32 weight blob in HBM (folded BN scale/shift, repacked conv weights). */
+bool EngineGetWeightBlob(ModelHandle handle, void** d_ptr, size_t* bytes, ErrorMessage* error);
+/* result = a + b on the GPU for host arrays (the reference's VectorAdd smoke test, cuda_utils.cu:59-149). */
+bool EngineVectorAdd(const float* a, const float* b, float* result, size_t n, ErrorMessage* error);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* INFERENCE_ENGINE_EXT_H */

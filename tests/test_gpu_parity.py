@@ -1,0 +1,268 @@
+"""GPU (-m gpu): the HIP engine, called through the C ABI exactly as the Go binding would, against the oracle and the
+committed float64 fixtures.  Tolerance: north_star's 1e-3 relative fp32 bar is the contract; the fp32 MFMA path is an exact
+fp32 FMA chain, so the tests hold it to 2e-4 of the output scale (and report the observed figure)."""
+import ctypes as C
+import os
+import subprocess
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import MINI, ROOT
+from gpu_ai_inference_server_amd import binding as B
+from gpu_ai_inference_server_amd import build
+from gpu_ai_inference_server_amd.modelgen import models
+from oracle import onnx_oracle as O
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(ROOT, "tests", "golden")
+RTOL = 2e-4   # of max|ref| ; contract (BASELINE.json north_star): 1e-3
+
+
+def rel_err(y, ref):
+    ref = np.asarray(ref, np.float64)
+    return float(np.abs(np.asarray(y, np.float64) - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def mgr(model_repo):
+    assert B.IsCUDAAvailable(), "no HIP device: the gpu tests must run on the MI355X box"
+    m = B.NewInferenceManager(model_repo)
+    yield m
+    m.Shutdown()
+
+
+def infer(mgr_or_model, name, iname, x, oname, oshape):
+    ins = [B.TensorData(iname, B.DataTypeFloat32, B.Shape(list(x.shape)), x)]
+    outs = [B.OutputConfig(oname, Shape=list(oshape), DataType="FLOAT32")]
+    if isinstance(mgr_or_model, B.Model):
+        r = mgr_or_model.Infer(ins, outs)
+    else:
+        r = mgr_or_model.RunInference(name, "", ins, outs)
+    return r[0].Data.reshape(r[0].Shape.Dims), r[0].Shape.Dims
+
+
+def test_device_queries():
+    assert B.GetDeviceCount() >= 1
+    info = B.GetDeviceInfo(0)
+    assert info.startswith("Device 0: ") and "(Compute Capability " in info      # cuda_utils.cu:51-54 format
+    mi = B.GetMemoryInfo(0)
+    assert mi.Total > 100e9 and mi.Used == mi.Total - mi.Free                    # 288 GB HBM3E part
+    assert B.GetDeviceInfo(4096) == "Unknown device"
+
+
+def test_vector_add_smoke():
+    """test/cuda_test.cpp:33-63: 1 M ones + twos -> threes."""
+    a = np.ones(1_000_000, np.float32)
+    b = np.full(1_000_000, 2.0, np.float32)
+    np.testing.assert_array_equal(B.VectorAdd(a, b), np.full(1_000_000, 3.0, np.float32))
+
+
+def test_test_model_known_answers(mgr):
+    g = np.load(os.path.join(GOLD, "test_model.npz"))
+    mgr.LoadModel("test_model")
+    try:
+        assert mgr.IsModelLoaded("test_model")
+        y, dims = infer(mgr, "test_model", "input", g["ort_recorded_input"], "output", [1, 2])
+        assert dims == [1, 2]
+        # the one result the reference recorded from ONNX Runtime 1.21.0 (docs/run_server.ipynb:174-175)
+        np.testing.assert_allclose(y, g["ort_recorded_output"], rtol=1e-6, atol=1e-7)
+        for x, ref in zip(g["inputs"], g["outputs_f64"]):
+            y, _ = infer(mgr, "test_model", "input", x[None], "output", [1, 2])
+            np.testing.assert_allclose(y[0], ref, rtol=2e-6, atol=1e-6)
+        m = mgr.GetModel("test_model")
+        st = m.GetStats()
+        assert st.InferenceCount == 1 + len(g["inputs"]) and st.MemoryUsageBytes == 10485780
+        assert st.TotalInferenceTimeNs >= st.LastInferenceTimeNs > 0
+        md = m.GetMetadata()
+        assert (md.Name, md.Version, md.Type, md.Inputs, md.Outputs) == ("test_model", "1", B.ModelONNX, ["input"], ["output"])
+        assert md.LoadTimeNs > 0
+        with pytest.raises(RuntimeError, match="Model already loaded"):
+            mgr.LoadModel("test_model")
+    finally:
+        mgr.UnloadModel("test_model")
+    assert not mgr.IsModelLoaded("test_model")
+
+
+def test_infer_validation_errors(mgr):
+    mgr.LoadModel("test_model")
+    try:
+        m = mgr.GetModel("test_model")
+        x = np.ones((1, 3), np.float32)
+        n0 = m.GetStats().InferenceCount
+        with pytest.raises(RuntimeError, match="Unexpected input name: data_0"):
+            infer(m, "", "data_0", x, "output", [1, 2])
+        two = [B.TensorData("input", 0, B.Shape([1, 3]), x)] * 2
+        with pytest.raises(RuntimeError, match="Expected 1 inputs, got 2"):
+            m.Infer(two, [B.OutputConfig("output", [1, 2])])
+        assert m.GetStats().InferenceCount == n0          # validation failures are not counted (model.cpp:566-569)
+        with pytest.raises(RuntimeError, match="Got invalid dimensions for input: input"):
+            infer(m, "", "input", np.ones((2, 3), np.float32), "output", [2, 2])
+        assert m.GetStats().InferenceCount == n0 + 1      # backend failures are (model.cpp:607-610)
+        # output buffer larger than produced: tail is zero-filled, dims clamp to the caller's rank
+        y, dims = infer(m, "", "input", x, "output", [1, 6])
+        assert dims == [1, 2] and np.all(y.ravel()[2:] == 0) and abs(y.ravel()[0] + 1.6748662) < 1e-5
+        # output buffer smaller than produced: only data_size bytes are written (bridge:810)
+        y, _ = infer(m, "", "input", x, "output", [1])
+        assert abs(y.ravel()[0] + 1.6748662) < 1e-5
+    finally:
+        mgr.UnloadModel("test_model")
+
+
+@pytest.mark.parametrize("name", sorted(MINI))
+def test_mini_graphs_vs_oracle_and_fixture(mgr, name):
+    mk, iname, ishape = MINI[name]
+    om = O.load_model(mk(models))
+    oname, oshape, _ = om.outputs[0]
+    x = models.synthetic_input(ishape, stream=name)
+    ref64 = np.load(os.path.join(GOLD, name + ".npz"))["output_f64"]
+    (yo,) = O.run(om, {iname: x}).values()
+    mgr.LoadModel(name)
+    try:
+        y, dims = infer(mgr, name, iname, x, oname, oshape)
+        assert dims == list(oshape)
+        e64, eo = rel_err(y, ref64), rel_err(y, yo)
+        print(f"{name}: rel err vs float64 fixture {e64:.2e}, vs oracle fp32 {eo:.2e}")
+        assert e64 < RTOL and eo < RTOL
+    finally:
+        mgr.UnloadModel(name)
+
+
+@pytest.mark.parametrize("tile", range(7))
+@pytest.mark.parametrize("algo", ["igemm", "scalar"])
+def test_every_igemm_tile_and_loader(model_repo, tile, algo):
+    """Each MFMA tile configuration x both operand loaders on graphs with ragged M / Cout / Cin tails."""
+    os.environ["IE_FORCE_TILE"] = str(tile)
+    os.environ["IE_FORCE_ALGO"] = algo
+    try:
+        for name in ("mini_densenet_scale", "mini_resnet_block", "mini_gemm_mlp"):
+            mk, iname, ishape = MINI[name]
+            om = O.load_model(mk(models))
+            oname, oshape, _ = om.outputs[0]
+            x = models.synthetic_input(ishape, stream=name)
+            ref64 = np.load(os.path.join(GOLD, name + ".npz"))["output_f64"]
+            m = B.CreateModel(os.path.join(model_repo, name, "1"), name)
+            try:
+                y, _ = infer(m, "", iname, x, oname, oshape)
+                assert rel_err(y, ref64) < RTOL, (name, tile, algo, rel_err(y, ref64))
+            finally:
+                m.Destroy()
+    finally:
+        del os.environ["IE_FORCE_TILE"], os.environ["IE_FORCE_ALGO"]
+
+
+def test_naive_kernel_agrees(model_repo):
+    os.environ["IE_FORCE_ALGO"] = "naive"
+    try:
+        name = "mini_densenet"
+        mk, iname, ishape = MINI[name]
+        x = models.synthetic_input(ishape, stream=name)
+        ref64 = np.load(os.path.join(GOLD, name + ".npz"))["output_f64"]
+        m = B.CreateModel(os.path.join(model_repo, name, "1"), name)
+        y, _ = infer(m, "", iname, x, "fc6_1", [2, 10, 1, 1])
+        m.Destroy()
+        assert rel_err(y, ref64) < RTOL
+    finally:
+        del os.environ["IE_FORCE_ALGO"]
+
+
+@pytest.fixture(scope="module")
+def densenet(densenet_repo):
+    m = B.CreateModel(os.path.join(densenet_repo, "densenet_onnx", "1"), "densenet_onnx")
+    yield m
+    m.Destroy()
+
+
+def test_densenet121_b2_vs_float64_fixture(densenet):
+    g = np.load(os.path.join(GOLD, "densenet121_b2.npz"))
+    x = models.synthetic_input((2, 3, 224, 224))
+    y, dims = infer(densenet, "", "data_0", x, "fc6_1", [2, 1000, 1, 1])
+    assert dims == [2, 1000, 1, 1]
+    e = rel_err(y.reshape(2, 1000), g["logits_f64"])
+    print(f"densenet121 B=2: rel err vs float64 fixture {e:.2e}")
+    assert e < RTOL
+    assert np.argmax(y.reshape(2, 1000), 1).tolist() == np.argmax(g["logits_f64"], 1).tolist()
+    md = densenet.GetMetadata()
+    assert md.Inputs == ["data_0"] and md.Outputs == ["fc6_1"]          # names come from the graph (fixes SURVEY §3.5-1)
+    assert densenet.GetStats().MemoryUsageBytes == 11091872
+
+
+def test_densenet121_b32_batch_independence(densenet):
+    """BASELINE configs[1] size.  Size-independent properties: every image's logits equal the logits of that image run
+    alone (shards are independent units), and a permutation of the batch permutes the outputs."""
+    x = models.synthetic_input((32, 3, 224, 224), stream="b32")
+    y32, _ = infer(densenet, "", "data_0", x, "fc6_1", [32, 1000, 1, 1])
+    y32 = y32.reshape(32, 1000)
+    assert np.isfinite(y32).all() and np.abs(y32).max() < 50
+    for i in (0, 13, 31):
+        y1, _ = infer(densenet, "", "data_0", x[i:i + 1], "fc6_1", [1, 1000, 1, 1])
+        assert rel_err(y1.reshape(1000), y32[i]) < 2e-5
+    perm = np.random.RandomState(0).permutation(32)
+    yp, _ = infer(densenet, "", "data_0", x[perm], "fc6_1", [32, 1000, 1, 1])
+    assert rel_err(yp.reshape(32, 1000), y32[perm]) < 2e-5
+    # oracle on two of the 32 images (seconds on CPU)
+    om = O.load_model(models.densenet121(2))
+    yo = O.run(om, {"data_0": x[[3, 27]]})["fc6_1"].reshape(2, 1000)
+    assert rel_err(y32[[3, 27]], yo) < RTOL
+
+
+def test_device_resident_path_matches_host_path(densenet):
+    """EnginePrepare/EngineRunPrepared (what bench.py times) produce the same bytes as ModelInfer."""
+    import torch
+    x = models.synthetic_input((4, 3, 224, 224), stream="dev")
+    y_host, _ = infer(densenet, "", "data_0", x, "fc6_1", [4, 1000, 1, 1])
+    din, dout = B.Prepare(densenet, [[4, 3, 224, 224]], 1)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert hip.hipMemcpy(din[0], x.ctypes.data, x.nbytes, 1) == 0
+    B.RunPrepared(densenet, 2, True)
+    y = np.empty((4, 1000), np.float32)
+    assert hip.hipMemcpy(y.ctypes.data, dout[0], y.nbytes, 2) == 0
+    np.testing.assert_array_equal(y, y_host.reshape(4, 1000))
+    prof = B.Profile(densenet, 1)
+    assert len(prof) == 126 and all(p["ms"] > 0 for p in prof)
+    ptr, nbytes = B.GetWeightBlob(densenet)
+    assert ptr and nbytes > 30e6
+    del torch
+
+
+def test_concurrent_infer_load_unload(mgr):
+    """gin serves each request on its own goroutine: concurrent ModelInfer on one handle plus registry traffic."""
+    mgr.LoadModel("mini_densenet")
+    mk, iname, ishape = MINI["mini_densenet"]
+    x = models.synthetic_input(ishape, stream="mini_densenet")
+    ref, _ = infer(mgr, "mini_densenet", iname, x, "fc6_1", [2, 10, 1, 1])
+    errs = []
+
+    def worker():
+        try:
+            for _ in range(20):
+                y, _ = infer(mgr, "mini_densenet", iname, x, "fc6_1", [2, 10, 1, 1])
+                np.testing.assert_array_equal(y, ref)
+                mgr.IsModelLoaded("mini_densenet"); mgr.ListModels()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=worker) for _ in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    h = mgr.GetModel("mini_densenet")
+    mgr.UnloadModel("mini_densenet")
+    assert not mgr.IsModelLoaded("mini_densenet")
+    del h
+
+
+def test_c_replay_harness_on_gpu(model_repo, engine_lib):
+    harness = build.build_harness() if not os.path.exists(os.path.join(os.path.dirname(engine_lib), "replay_binding")) \
+        else os.path.join(os.path.dirname(engine_lib), "replay_binding")
+    r = subprocess.run([harness, model_repo, "test_model", "input", "output", "2", "1", "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = dict(l.split(" -> ", 1) for l in r.stdout.splitlines() if l.startswith("CALL "))
+    assert out["CALL InferenceLoadModel"].strip() == "1" and out["CALL InferenceLoadModel(again)"] == "0 error=Model already loaded"
+    assert out["CALL ModelInfer"].strip() == "1" and out["CALL ModelIsLoaded(after unload)"] == "0"
+    assert out["CALL InferenceUnloadModel(again)"] == "0 error=Model not found"
+    vals = [float(v) for v in [l for l in r.stdout.splitlines() if l.startswith("OUTPUT ")][0].split()[1:]]
+    np.testing.assert_allclose(vals, [-1.6748662, 2.0709436], rtol=2e-6)   # ones(1,3) probe (test/onnx_test.cpp:92), SURVEY §8c
+    assert "count=1 mem=10485780" in out["CALL ModelGetStats"]

@@ -1,0 +1,91 @@
+"""CPU: the ONNX reader + graph planner (host logic of the engine) through the C ABI's EngineDescribeModel."""
+import os
+
+import numpy as np
+import pytest
+
+from gpu_ai_inference_server_amd import binding as B
+from gpu_ai_inference_server_amd.modelgen import models
+from gpu_ai_inference_server_amd.modelgen import onnx_pb as pb
+from oracle import onnx_oracle as O
+
+
+def test_describe_test_model_known_answers(model_repo):
+    d = B.DescribeModel(os.path.join(model_repo, "test_model", "1"), 1)
+    assert (d["ir_version"], d["opset"], d["producer"], d["num_nodes"], d["num_initializers"]) == (10, 12, "GPU-AI-Inference-Server", 5, 4)
+    assert d["inputs"] == [{"name": "input", "elem_type": 1, "dims": [1, 3]}]
+    assert d["outputs"] == [{"name": "output", "elem_type": 1, "dims": [1, 2]}]
+    assert d["memory_usage_bytes"] == 10485780                       # model.cpp:979-1035 on this graph
+    steps = d["plan"]["steps"]
+    assert [s["name"] for s in steps] == ["matmul1+add1+relu", "matmul2+add2"]      # MatMul+Add(+Relu) fused into two GEMM steps
+    assert steps[0]["relu"] and steps[0]["bias"] and not steps[1]["relu"]
+
+
+def test_describe_agrees_with_oracle_reader(model_repo):
+    for name in ("mini_densenet", "mini_densenet_scale", "mini_gemm_mlp", "mini_resnet_block"):
+        path = os.path.join(model_repo, name, "1")
+        d = B.DescribeModel(path)
+        m = O.load_model(open(os.path.join(path, "model.onnx"), "rb").read())
+        assert d["num_nodes"] == len(m.nodes) and d["num_initializers"] == len(m.inits)
+        assert [(i["name"], i["dims"]) for i in d["inputs"]] == [(n, s) for n, s, _ in m.inputs]
+        assert [(o["name"], o["dims"]) for o in d["outputs"]] == [(n, s) for n, s, _ in m.outputs]
+        assert d["memory_usage_bytes"] == O.estimate_memory_usage(m)
+
+
+def test_densenet121_plan(densenet_repo):
+    d = B.DescribeModel(os.path.join(densenet_repo, "densenet_onnx", "1"), 32)
+    assert d["inputs"][0] == {"name": "data_0", "elem_type": 1, "dims": [-1, 3, 224, 224]}
+    assert d["outputs"][0]["name"] == "fc6_1" and d["outputs"][0]["dims"] == [-1, 1000, 1, 1]
+    assert d["memory_usage_bytes"] == 11091872                       # SURVEY §8 a7 known-answer (dynamic dim skipped)
+    p = d["plan"]
+    kinds = [s["kind"] for s in p["steps"]]
+    # 121 convs, stem max-pool + 3 transition avg-pools, 1 global pool; every BN/ReLU/Concat fused away
+    assert kinds.count("conv") == 121 and kinds.count("pool") == 4 and kinds.count("gap") == 1 and len(kinds) == 126
+    assert abs(p["total_flops"] / 32 / 5.668e9 - 1) < 2e-3            # 5.668 GFLOP per image
+    act = sum(s["bytes"] for s in p["steps"]) / 32
+    assert 94e6 < act < 98e6                                          # 23.8 M activation elements (+weights/32)
+    # dense block 1: six 3x3 convs write 32-channel slices at offsets 64..224 of one 256-channel NHWC buffer
+    grow = [s for s in p["steps"] if s["kind"] == "conv" and s["k"] == [3, 3] and s["out"]["pitch"] == 256]
+    assert [s["out"]["c_off"] for s in grow] == [64, 96, 128, 160, 192, 224]
+    assert len({s["out"]["buf"] for s in grow}) == 1
+    # pre-activation BN+ReLU rides on the consumer conv, Conv->BN->ReLU on the producer
+    b1 = [s for s in p["steps"] if s["kind"] == "conv" and s["k"] == [1, 1] and s["in"]["pitch"] == 256]
+    assert all(s["pre"] and s["pre_relu"] and s["relu"] and s["bias"] for s in b1[:6])
+    assert p["steps"][0]["algo"] == "igemm_scalar" and p["steps"][0]["in"]["nchw"]      # stem reads the ABI's NCHW directly
+    assert all(s["algo"] == "igemm_vec" for s in p["steps"][2:] if s["kind"] == "conv")
+    assert p["outputs"][0]["dims"] == [32, 1000, 1, 1]
+    # recycled activation buffers: far fewer buffers than tensors, working set < 256 MiB Infinity Cache + input
+    assert len(p["buffers"]) <= 12 and sum(p["buffers"]) * 4 < 320e6
+
+
+def test_batch_mismatch_and_unsupported_ops(tmp_path, model_repo):
+    with pytest.raises(RuntimeError, match="ONNX model file not found"):
+        B.DescribeModel(str(tmp_path / "missing"))
+    # fixed-batch model (test_model is [1,3]) rejects another batch like ORT does
+    g = pb.graph("g", [pb.node("Relu", ["x"], ["y"], "r")], [], [pb.value_info("x", [2, 4])], [pb.value_info("y", [2, 4])])
+    p = tmp_path / "relu.onnx"
+    p.write_bytes(pb.model(g))
+    d = B.DescribeModel(str(p), 2)
+    assert [s["kind"] for s in d["plan"]["steps"]] == ["eltwise"]
+    g = pb.graph("g", [pb.node("Softplus", ["x"], ["y"], "sp")], [], [pb.value_info("x", [1, 4])], [pb.value_info("y", [1, 4])])
+    p2 = tmp_path / "bad.onnx"
+    p2.write_bytes(pb.model(g))
+    with pytest.raises(RuntimeError, match=r"Unsupported ONNX operator: Softplus \(node sp\)"):
+        B.DescribeModel(str(p2), 1)
+    p3 = tmp_path / "garbage.onnx"
+    p3.write_bytes(b"\x0a\xff\xff\xff\xff\xff\xff\xff\xff\xff\xff\x01 not a protobuf")
+    with pytest.raises(RuntimeError, match="ONNX parse error"):
+        B.DescribeModel(str(p3), 1)
+
+
+def test_packed_and_unpacked_attribute_encodings(tmp_path):
+    """protobuf allows both encodings of repeated ints; ORT accepts both, so must the reader."""
+    w = np.ones((4, 4, 3, 3), np.float32)
+    for packed in (False, True):
+        n = pb.node("Conv", ["x", "w"], ["y"], "c", [pb.attr_ints("kernel_shape", [3, 3], packed), pb.attr_ints("pads", [1, 1, 1, 1], packed),
+                                                        pb.attr_ints("strides", [2, 2], packed)])
+        g = pb.graph("g", [n], [pb.tensor("w", w, raw=not packed)], [pb.value_info("x", [1, 4, 8, 8])], [pb.value_info("y", [1, 4, 4, 4])])
+        f = tmp_path / f"c{int(packed)}.onnx"
+        f.write_bytes(pb.model(g))
+        s = B.DescribeModel(str(f), 1)["plan"]["steps"][0]
+        assert (s["k"], s["stride"], s["pads"], s["out"]["h"], s["out"]["w"]) == ([3, 3], [2, 2], [1, 1, 1, 1], 4, 4)
