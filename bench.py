@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec + p50 latency of DenseNet-121 fp32, batch 32 per GPU, device-resident inputs.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one forward pass of the hot path (the captured hipGraph of the fused DenseNet-121 plan) over one batch of
+synthetic 3x224x224 images that already sit in the engine's HBM input buffer.  Weak scaling: every rank owns an
+independent shard of `--batch` images (no data-path collective); the only RCCL traffic is the load-time weight
+broadcast from rank 0.  Rank 0 prints ONE JSON line (contract in the task statement) extended with
+
+  roofline      dominant kernel family (conv_igemm_kernel = MFMA implicit-GEMM conv): algorithmic FLOPs per launch /
+                average launch duration, measured with HIP events on the model's stream in an instrumented eager pass
+                of the same forward (EngineProfile), against the 157.3 TFLOP/s dense fp32 MFMA peak
+  cpu_baseline  the oracle (numpy restatement of the ONNX ops, oracle/onnx_oracle.py) timed on this host on a bounded
+                sample of the same workload; kind "port" — it is NOT ONNX Runtime (absent from the image)
+  p50_ms, modelinfer_*   per-call latency of the device-resident step and of the full ModelInfer C-ABI call
+                (host buffers, PCIe-inclusive; never used for `value`)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_HBM_GBS = 8000.0
+
+
+def model_dir() -> str:
+    from gpu_ai_inference_server_amd.modelgen import models
+    root = os.environ.get("IE_BENCH_MODEL_ROOT", "/tmp/ie_bench_models")
+    path = os.path.join(root, "densenet_onnx", "1", "model.onnx")
+    if not os.path.exists(path):
+        models.write_repo(root, "densenet_onnx", models.densenet121("N"))
+    return os.path.join(root, "densenet_onnx", "1")
+
+
+def cpu_baseline(sample_images: int) -> dict:
+    """Oracle (CPU restatement, numpy/OpenBLAS) on `sample_images` images of the same synthetic workload."""
+    from gpu_ai_inference_server_amd.modelgen import models
+    from oracle import onnx_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:  # noqa: BLE001
+        cores = os.cpu_count() or 1
+    m = O.load_model(models.densenet121(sample_images))
+    x = models.synthetic_input((sample_images, 3, 224, 224), stream="bench")
+    O.run(m, {"data_0": x[:1]})                      # warm BLAS threads / page in
+    t0 = time.perf_counter()
+    O.run(m, {"data_0": x})
+    dt = time.perf_counter() - t0
+    return {"value": round(sample_images / dt, 3), "unit": "images/sec", "cores": int(cores), "kind": "port",
+            "sample": f"{sample_images} images of the same synthetic DenseNet-121 fp32 workload, one oracle forward "
+                      f"(numpy im2col + BLAS, {dt:.1f} s); stand-in for the absent ONNX Runtime CPU EP"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--cpu-sample", type=int, default=8, help="images for the CPU baseline (0 = skip)")
+    ap.add_argument("--no-hostpath", action="store_true", help="skip the ModelInfer (PCIe-inclusive) measurement")
+    args = ap.parse_args()
+
+    from _pkg import load_package
+    load_package()
+    from gpu_ai_inference_server_amd import binding as B
+    from gpu_ai_inference_server_amd import sharding
+    from gpu_ai_inference_server_amd.modelgen import models
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
+
+    if not B.IsCUDAAvailable():
+        raise SystemExit("bench.py needs a HIP device (the engine has no CPU fallback)")
+
+    # rank 0 writes the synthetic model file once; the others wait for it
+    if rank == 0:
+        mdir = model_dir()
+    if dist is not None:
+        dist.barrier()
+    mdir = model_dir()
+
+    model = B.CreateModel(mdir, "densenet_onnx", device_id=local_rank)
+    Bsz = args.batch
+    din, dout = B.Prepare(model, [[Bsz, 3, 224, 224]], 1)
+    x = models.synthetic_input((Bsz, 3, 224, 224), stream=f"bench/rank{rank}")
+    B.CopyToDevice(model, din[0], x)                 # inputs resident in HBM before any timing
+
+    if dist is not None:                             # load-time weight exchange: one RCCL broadcast over xGMI
+        import torch
+        blob = B.GetWeightBlob(model)
+        sharding.broadcast_weights(dist, blob, src=0)
+        torch.cuda.synchronize()
+
+    def barrier():
+        B.Synchronize(model)
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    B.RunPrepared(model, args.warmup, True)
+    barrier()
+    t0 = time.perf_counter()
+    B.RunPrepared(model, args.steps, True)           # EXACTLY K steps, back-to-back graph replays, then sync
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-call latency of the device-resident step (sync after every step)
+    lat = []
+    for _ in range(min(args.steps, 50)):
+        t1 = time.perf_counter()
+        B.RunPrepared(model, 1, True)
+        lat.append((time.perf_counter() - t1) * 1e3)
+    p50 = float(np.percentile(lat, 50))
+
+    y = np.empty((Bsz, 1000), np.float32)
+    B.CopyToHost(model, y, dout[0])
+    assert np.isfinite(y).all()
+
+    result = None
+    if rank == 0:
+        total_images = Bsz * world * args.steps
+        result = {
+            "metric": "images/sec, DenseNet-121 fp32, batch 32 per GPU, device-resident inputs (+ p50 step latency)",
+            "value": round(total_images / elapsed, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "DenseNet-121 fp32 batch=32 per GPU, synthetic 3x224x224 inputs (BASELINE configs[1]); "
+                                   "synthetic ONNX graph + seeded random weights (reference model file is not in the mount)",
+                       "global_batch": Bsz * world, "per_gpu_batch": Bsz, "parallelism": f"dp{world} (independent batch shards)"},
+            "p50_ms": round(p50, 4),
+        }
+        # ---- roofline of the dominant kernel family, HIP events on the model's stream --------------------------
+        prof = B.Profile(model, 5)
+        fam = {}
+        for p in prof:
+            k = p["kernel"].split("<")[0]
+            f = fam.setdefault(k, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
+            f["ms"] += p["ms"]; f["flops"] += p["flops"]; f["bytes"] += p["bytes"]; f["launches"] += 1
+        dom = max(fam, key=lambda k: fam[k]["ms"])
+        d = fam[dom]
+        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        result["roofline"] = {
+            "kernel": dom, "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "launches_per_step": d["launches"], "flops_per_launch": round(d["flops"] / d["launches"], 1),
+            "avg_launch_ms": round(d["ms"] / d["launches"], 6),
+            "note": "algorithmic FLOPs (2*M*N*K summed over the family's launches of one forward) / sum of their HIP-event "
+                    "durations in an eager instrumented pass; traffic: see profiles/ (PMC pass)",
+        }
+        result["kernel_families_ms"] = {k: round(v["ms"], 4) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
+        result["eager_forward_ms"] = round(sum(p["ms"] for p in prof), 4)
+        # ---- full C-ABI call with host buffers (PCIe-inclusive; reported, never `value`) -----------------------
+        if not args.no_hostpath:
+            ins = [B.TensorData("data_0", B.DataTypeFloat32, B.Shape([Bsz, 3, 224, 224]), x)]
+            outs = [B.OutputConfig("fc6_1", [Bsz, 1000, 1, 1])]
+            for _ in range(3):
+                model.Infer(ins, outs)
+            hl = []
+            for _ in range(10):
+                t1 = time.perf_counter()
+                model.Infer(ins, outs)
+                hl.append(time.perf_counter() - t1)
+            result["modelinfer_p50_ms"] = round(float(np.percentile(hl, 50)) * 1e3, 3)
+            result["modelinfer_images_per_s"] = round(Bsz / float(np.percentile(hl, 50)), 1)
+        if args.cpu_sample > 0:
+            result["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+        else:
+            result["cpu_baseline"] = None
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    model.Destroy()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

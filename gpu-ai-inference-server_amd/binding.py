@@ -69,7 +69,7 @@ ABI_SYMBOLS = [
     "ModelLoad", "ModelUnload",
 ]
 EXT_SYMBOLS = ["EngineDescribeModel", "EnginePrepare", "EngineRunPrepared", "EngineSynchronize", "EngineGetStream",
-               "EngineProfile", "EngineGetWeightBlob", "EngineVectorAdd"]
+               "EngineProfile", "EngineGetWeightBlob", "EngineMemcpy", "EngineVectorAdd"]
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -111,6 +111,7 @@ def lib() -> C.CDLL:
             "EngineGetStream": (vp, [vp]), "EngineProfile": (vp, [vp, C.c_int, ep]),
             "EngineGetWeightBlob": (C.c_bool, [vp, ep, C.POINTER(C.c_size_t), ep]),
             "EngineVectorAdd": (C.c_bool, [vp, vp, vp, C.c_size_t, ep]),
+            "EngineMemcpy": (C.c_bool, [vp, vp, vp, C.c_size_t, C.c_int, ep]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)   # AttributeError here = symbol missing from the .so
@@ -490,6 +491,20 @@ def GetWeightBlob(model: Model):
     if not lib().EngineGetWeightBlob(model.handle, C.byref(ptr), C.byref(nbytes), C.byref(err)):
         raise RuntimeError("weight blob unavailable: " + _take_error(err))
     return int(ptr.value or 0), int(nbytes.value)
+
+
+def CopyToDevice(model: Model, dst_dev: int, src: np.ndarray) -> None:
+    src = np.ascontiguousarray(src)
+    err = C.c_void_p()
+    if not lib().EngineMemcpy(model.handle, dst_dev, src.ctypes.data, src.nbytes, 1, C.byref(err)):
+        raise RuntimeError(_take_error(err))
+
+
+def CopyToHost(model: Model, dst: np.ndarray, src_dev: int) -> None:
+    assert dst.flags["C_CONTIGUOUS"]
+    err = C.c_void_p()
+    if not lib().EngineMemcpy(model.handle, dst.ctypes.data, src_dev, dst.nbytes, 2, C.byref(err)):
+        raise RuntimeError(_take_error(err))
 
 
 def VectorAdd(a: np.ndarray, b: np.ndarray) -> np.ndarray:

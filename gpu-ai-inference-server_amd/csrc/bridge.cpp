@@ -597,6 +597,21 @@ bool EngineGetWeightBlob(ModelHandle handle, void** d_ptr, size_t* bytes, ErrorM
     catch (...) { set_error(error, "unknown error"); return false; }
 }
 
+bool EngineMemcpy(ModelHandle handle, void* dst, const void* src, size_t bytes, int kind, ErrorMessage* error) {
+    if (!handle || !dst || !src || kind < 1 || kind > 3) { set_error(error, "Invalid parameters"); return false; }
+    try {
+        ModelObj& M = *handle->model;
+        std::lock_guard<std::mutex> g(M.mu);
+        if (!M.loaded.load() || !M.dev) { set_error(error, "Model not loaded"); return false; }
+        M.dev->Synchronize();
+        hipMemcpyKind k = kind == 1 ? hipMemcpyHostToDevice : (kind == 2 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice);
+        hipError_t e = hipMemcpy(dst, src, bytes, k);
+        if (e != hipSuccess) { set_error(error, std::string("HIP error in hipMemcpy: ") + hipGetErrorString(e)); return false; }
+        return true;
+    } catch (const std::exception& e) { set_error(error, e.what()); return false; }
+    catch (...) { set_error(error, "unknown error"); return false; }
+}
+
 bool EngineVectorAdd(const float* a, const float* b, float* result, size_t n, ErrorMessage* error) {
     if (!a || !b || !result) { set_error(error, "Invalid parameters"); return false; }
     if (ie::HipDeviceCount() <= 0) { set_error(error, "No HIP device available"); return false; }

@@ -34,6 +34,9 @@ void* EngineGetStream(ModelHandle handle);
 char* EngineProfile(ModelHandle handle, int iters, ErrorMessage* error);
 /* Packed fp32 weight blob in HBM (folded BN scale/shift, repacked conv weights). */
 bool EngineGetWeightBlob(ModelHandle handle, void** d_ptr, size_t* bytes, ErrorMessage* error);
+/* Synchronous hipMemcpy on the model's device: kind 1 = host->device, 2 = device->host, 3 = device->device.
+ * Lets a test or benchmark fill / read the engine-owned buffers returned by EnginePrepare. */
+bool EngineMemcpy(ModelHandle handle, void* dst, const void* src, size_t bytes, int kind, ErrorMessage* error);
 /* result = a + b on the GPU for host arrays (the reference's VectorAdd smoke test, cuda_utils.cu:59-149). */
 bool EngineVectorAdd(const float* a, const float* b, float* result, size_t n, ErrorMessage* error);
 
