@@ -82,6 +82,7 @@ DeviceModel::~DeviceModel() {
     for (auto& kv : plans_) {
         if (kv.second->graph_exec) (void)hipGraphExecDestroy(kv.second->graph_exec);
         for (float* b : kv.second->buffers) if (b) (void)hipFree(b);
+        if (kv.second->workspace) (void)hipFree(kv.second->workspace);
     }
     if (d_weights_) (void)hipFree(d_weights_);
     if (pinned_) (void)hipHostFree(pinned_);
@@ -114,6 +115,11 @@ PlanInstance& DeviceModel::Prepare(const std::vector<std::vector<int64_t>>& shap
         check(hipMemsetAsync(p, 0, bytes, stream_), "hipMemset(activations)");
         device_bytes_ += bytes;
         pi->buffers.push_back(p);
+    }
+    if (pi->plan.workspace_floats > 0) {
+        size_t bytes = size_t(pi->plan.workspace_floats) * sizeof(float);
+        check(hipMalloc(reinterpret_cast<void**>(&pi->workspace), bytes), "hipMalloc(workspace)");
+        device_bytes_ += bytes;
     }
     check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
 
@@ -152,8 +158,9 @@ void DeviceModel::LaunchStep(const PlanInstance& pi, const Step& s) {
             a.pre_shift = wp(s.pre_shift_off);
             a.kh = s.kh; a.kw = s.kw; a.sh = s.sh; a.sw = s.sw; a.pt = s.pt; a.pl = s.pl;
             a.pre_relu = s.pre_relu; a.relu = s.relu;
+            a.workspace = pi.workspace;
             if (s.algo == ConvAlgo::Naive) check(LaunchConvNaive(a, stream_), "conv_naive");
-            else check(LaunchConvIgemm(a, s.tile, s.algo == ConvAlgo::IgemmVec ? 1 : 0, stream_), "conv_igemm");
+            else check(LaunchConvIgemm(a, s.tile, s.algo == ConvAlgo::IgemmVec ? 1 : 0, s.splitk, stream_), "conv_igemm");
             break;
         }
         case StepKind::Pool: {
@@ -191,7 +198,8 @@ static std::string kernel_label(const Step& s) {
         case StepKind::Conv:
             if (s.algo == ConvAlgo::Naive) return "conv_naive_kernel";
             return std::string("conv_igemm_kernel<") + std::to_string(kIgemmTiles[s.tile].bm) + "x" +
-                   std::to_string(kIgemmTiles[s.tile].bn) + (s.algo == ConvAlgo::IgemmVec ? ",vec>" : ",scalar>");
+                   std::to_string(kIgemmTiles[s.tile].bn) + (s.algo == ConvAlgo::IgemmVec ? ",vec" : ",scalar") +
+                   (s.splitk > 1 ? ",splitk" + std::to_string(s.splitk) : std::string()) + ">";
         case StepKind::Pool: return "pool_kernel";
         case StepKind::GlobalAvgPool: return "gap_kernel";
         case StepKind::Eltwise: return "eltwise_kernel";

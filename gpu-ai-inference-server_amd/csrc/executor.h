@@ -24,6 +24,7 @@ struct StepTiming {
 struct PlanInstance {
     Plan plan;
     std::vector<float*> buffers;       // device activation buffers (plan.buffer_floats)
+    float* workspace = nullptr;        // split-K slabs (plan.workspace_floats)
     hipGraphExec_t graph_exec = nullptr;
     bool graph_ready = false;
 };

@@ -23,6 +23,7 @@ struct ConvArgs {
     const float* pre_shift = nullptr;
     int kh = 1, kw = 1, sh = 1, sw = 1, pt = 0, pl = 0;
     int pre_relu = 0, relu = 0;
+    float* workspace = nullptr;        // split-K partial slabs [splitk][M][Cout] (only when splitk > 1)
 };
 
 struct PoolArgs {
@@ -39,7 +40,9 @@ struct EltArgs {
 };
 
 // vec: 1 = float4 NHWC operand staging, 0 = scalar gather staging.  tile: index into kIgemmTiles.
-hipError_t LaunchConvIgemm(const ConvArgs& a, int tile, int vec, hipStream_t stream);
+// splitk > 1: the K-tiles are divided over grid.y workgroups that write partial slabs to a.workspace, then a
+// second kernel sums the slabs and applies bias/ReLU (deterministic: no atomics).
+hipError_t LaunchConvIgemm(const ConvArgs& a, int tile, int vec, int splitk, hipStream_t stream);
 hipError_t LaunchConvNaive(const ConvArgs& a, hipStream_t stream);
 hipError_t LaunchPool(const PoolArgs& a, hipStream_t stream);
 // out[n, c] = mean over (y, x) of f(in[n, y, x, c]),  f = optional scale/shift/ReLU prologue

@@ -98,6 +98,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
         }
     };
 
+    // K-range of this workgroup (split-K: grid.y slices the K-tiles; partial sums go to a workspace slab)
+    const int nsplit = gridDim.y, split = blockIdx.y;
+
     if constexpr (VEC) {
         // ---- float4 staging: thread owns column-quad `c4` of rows {rw + i*ROWS_PER_PASS} ----------------
         constexpr int ROWS_PER_PASS = NT / 8;
@@ -107,55 +110,61 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
         const int rw = tid >> 3;
         const int cblocks = (Cin + BK - 1) / BK;
         const int KT = a.kh * a.kw * cblocks;
+        const int kt_begin = int(int64_t(KT) * split / nsplit), kt_end = int(int64_t(KT) * (split + 1) / nsplit);
 
-        int iy0[A_IT], ix0[A_IT];
-        int64_t rbase[A_IT];
+        // All element offsets fit 32 bits (LaunchConvIgemm rejects views of >= 2^31 floats).
+        const int isn = int(a.in.sn), ish = int(a.in.sh), isw = int(a.in.sw);
+        int iy0[A_IT], ix0[A_IT], rbase[A_IT];
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int m = m0 + rw + i * ROWS_PER_PASS;
-            if (m < M) {
-                const int b = m / (OH * OW);
-                const int rem = m - b * (OH * OW);
-                const int oy = rem / OW, ox = rem - oy * OW;
-                iy0[i] = oy * a.sh - a.pt;
-                ix0[i] = ox * a.sw - a.pl;
-                rbase[i] = int64_t(b) * a.in.sn;
-            } else {
-                iy0[i] = -(1 << 28);    // every tap falls outside -> zero rows
-                ix0[i] = 0;
-                rbase[i] = 0;
-            }
+            const bool mok = m < M;
+            const int mm = mok ? m : 0;
+            const int b = mm / (OH * OW);
+            const int rem = mm - b * (OH * OW);
+            const int oy = rem / OW, ox = rem - oy * OW;
+            iy0[i] = mok ? oy * a.sh - a.pt : -(1 << 28);    // every tap of a tail row falls outside -> zeros
+            ix0[i] = ox * a.sw - a.pl;
+            rbase[i] = b * isn;
         }
         f32x4 ra[A_IT], rb[B_IT];
-        auto load_tile = [&](int kt) {
+        f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
+        unsigned okmask = 0;     // bit i: A row i valid, bit 16+i: B row i valid
+        // Phase 1: issue the global loads of K-tile kt (raw values; nothing here depends on their arrival).
+        auto issue_loads = [&](int kt) {
             const int tap = kt / cblocks;
             const int c = (kt - tap * cblocks) * BK + c4;
             const int ky = tap / a.kw, kx = tap - ky * a.kw;
             const bool cok = c < Cin;
-            f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
+            okmask = 0;
             if (has_pre) {
                 const int cc = cok ? c : 0;
                 s4 = *reinterpret_cast<const f32x4*>(a.pre_scale + cc);
                 t4 = *reinterpret_cast<const f32x4*>(a.pre_shift + cc);
             }
-            bool ok[A_IT];
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
                 const int iy = iy0[i] + ky, ix = ix0[i] + kx;
-                ok[i] = cok && unsigned(iy) < unsigned(H) && unsigned(ix) < unsigned(W);
-                // unconditional load from a clamped address (keeps the loads batched; no per-load branch)
-                const int64_t off = ok[i] ? rbase[i] + int64_t(iy) * a.in.sh + int64_t(ix) * a.in.sw + c : 0;
+                const bool ok = cok && unsigned(iy) < unsigned(H) && unsigned(ix) < unsigned(W);
+                okmask |= ok ? (1u << i) : 0u;
+                // unconditional load from a clamped address: keeps all loads of the tile in flight together
+                int off = rbase[i] + iy * ish + ix * isw + c;
+                off = ok ? off : 0;
                 ra[i] = *reinterpret_cast<const f32x4*>(in + off);
             }
 #pragma unroll
             for (int i = 0; i < B_IT; ++i) {
                 const int n = n0 + rw + i * ROWS_PER_PASS;
                 const bool bok = cok && n < Cout;
-                const int64_t off = bok ? int64_t(n) * Ktot + tap * Cin + c : 0;
-                f32x4 v = *reinterpret_cast<const f32x4*>(wgt + off);
-                if (!bok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                rb[i] = v;
+                okmask |= bok ? (1u << (16 + i)) : 0u;
+                int off = n * Ktot + tap * Cin + c;
+                off = bok ? off : 0;
+                rb[i] = *reinterpret_cast<const f32x4*>(wgt + off);
             }
+        };
+        // Phase 3 (after the MFMAs of the previous tile): activation prologue, zero padding, LDS store.
+        auto finish_store = [&](int buf) {
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
                 f32x4 v = ra[i];
@@ -165,28 +174,31 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
                         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                     }
                 }
-                if (!ok[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};   // zero padding is applied AFTER the activation
-                ra[i] = v;
+                if (!(okmask & (1u << i))) v = zero;      // zero padding is applied AFTER the activation
+                *reinterpret_cast<f32x4*>(sA + buf * BM * LDP + (rw + i * ROWS_PER_PASS) * LDP + c4) = v;
+            }
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) {
+                f32x4 v = rb[i];
+                if (!(okmask & (1u << (16 + i)))) v = zero;
+                *reinterpret_cast<f32x4*>(sB + buf * BN * LDP + (rw + i * ROWS_PER_PASS) * LDP + c4) = v;
             }
         };
-        auto store_tile = [&](int buf) {
-#pragma unroll
-            for (int i = 0; i < A_IT; ++i)
-                *reinterpret_cast<f32x4*>(sA + buf * BM * LDP + (rw + i * ROWS_PER_PASS) * LDP + c4) = ra[i];
-#pragma unroll
-            for (int i = 0; i < B_IT; ++i)
-                *reinterpret_cast<f32x4*>(sB + buf * BN * LDP + (rw + i * ROWS_PER_PASS) * LDP + c4) = rb[i];
-        };
 
-        load_tile(0);
-        store_tile(0);
-        __syncthreads();
-        for (int kt = 0; kt < KT; ++kt) {
-            const int buf = kt & 1;
-            if (kt + 1 < KT) load_tile(kt + 1);
-            compute(buf);
-            if (kt + 1 < KT) store_tile(buf ^ 1);
+        if (kt_begin < kt_end) {
+            issue_loads(kt_begin);
+            finish_store(0);
             __syncthreads();
+            for (int kt = kt_begin; kt < kt_end; ++kt) {
+                const int buf = (kt - kt_begin) & 1;
+                const bool more = kt + 1 < kt_end;
+                if (more) issue_loads(kt + 1);
+                __builtin_amdgcn_sched_barrier(0);       // loads stay ahead of the MFMA block ...
+                compute(buf);
+                __builtin_amdgcn_sched_barrier(0);       // ... and their consumers stay behind it
+                if (more) finish_store(buf ^ 1);
+                __syncthreads();
+            }
         }
     } else {
         // ---- scalar gather staging: any Cin, any input strides (NCHW stem) ------------------------------
@@ -214,72 +226,127 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
         const int col = tid & (BK - 1);
         const int rw = tid / BK;
         const int KT = (Ktot + BK - 1) / BK;
+        const int kt_begin = int(int64_t(KT) * split / nsplit), kt_end = int(int64_t(KT) * (split + 1) / nsplit);
         float ra[A_IT], rb[B_IT];
-        auto load_tile = [&](int kt) {
+        float ps = 1.f, pt = 0.f;
+        unsigned okA = 0, okB = 0;
+        auto issue_loads = [&](int kt) {
             const int k = kt * BK + col;
             const bool kok = k < Ktot;
             const int kk = kok ? k : 0;
             const int tap = kk / Cin;
             const int c = kk - tap * Cin;
             const int ky = tap / a.kw, kx = tap - ky * a.kw;
-            float s = 1.f, t = 0.f;
-            if (has_pre) { s = a.pre_scale[c]; t = a.pre_shift[c]; }
+            if (has_pre) { ps = a.pre_scale[c]; pt = a.pre_shift[c]; }
+            okA = 0; okB = 0;
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
                 const int row = rw + i * ROWS_PER_PASS;
                 const int iy = s_iy0[row] + ky, ix = s_ix0[row] + kx;
                 const bool ok = kok && unsigned(iy) < unsigned(H) && unsigned(ix) < unsigned(W);
+                okA |= ok ? (1u << i) : 0u;
                 const int64_t off = ok ? s_rbase[row] + int64_t(iy) * a.in.sh + int64_t(ix) * a.in.sw + int64_t(c) * a.in.sc : 0;
-                float v = in[off];
-                if (has_pre) { v = v * s + t; if (a.pre_relu) v = fmaxf(v, 0.f); }
-                ra[i] = ok ? v : 0.f;
+                ra[i] = in[off];
             }
 #pragma unroll
             for (int i = 0; i < B_IT; ++i) {
                 const int n = n0 + rw + i * ROWS_PER_PASS;
                 const bool bok = kok && n < Cout;
-                const float v = wgt[bok ? int64_t(n) * Ktot + k : 0];
-                rb[i] = bok ? v : 0.f;
+                okB |= bok ? (1u << i) : 0u;
+                rb[i] = wgt[bok ? int64_t(n) * Ktot + k : 0];
             }
         };
-        auto store_tile = [&](int buf) {
+        auto finish_store = [&](int buf) {
 #pragma unroll
-            for (int i = 0; i < A_IT; ++i) sA[buf * BM * LDP + (rw + i * ROWS_PER_PASS) * LDP + col] = ra[i];
+            for (int i = 0; i < A_IT; ++i) {
+                float v = ra[i];
+                if (has_pre) { v = v * ps + pt; if (a.pre_relu) v = fmaxf(v, 0.f); }
+                if (!(okA & (1u << i))) v = 0.f;
+                sA[buf * BM * LDP + (rw + i * ROWS_PER_PASS) * LDP + col] = v;
+            }
 #pragma unroll
-            for (int i = 0; i < B_IT; ++i) sB[buf * BN * LDP + (rw + i * ROWS_PER_PASS) * LDP + col] = rb[i];
+            for (int i = 0; i < B_IT; ++i)
+                sB[buf * BN * LDP + (rw + i * ROWS_PER_PASS) * LDP + col] = (okB & (1u << i)) ? rb[i] : 0.f;
         };
-        load_tile(0);
-        store_tile(0);
-        __syncthreads();
-        for (int kt = 0; kt < KT; ++kt) {
-            const int buf = kt & 1;
-            if (kt + 1 < KT) load_tile(kt + 1);
-            compute(buf);
-            if (kt + 1 < KT) store_tile(buf ^ 1);
+        if (kt_begin < kt_end) {
+            issue_loads(kt_begin);
+            finish_store(0);
             __syncthreads();
+            for (int kt = kt_begin; kt < kt_end; ++kt) {
+                const int buf = (kt - kt_begin) & 1;
+                const bool more = kt + 1 < kt_end;
+                if (more) issue_loads(kt + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(buf);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) finish_store(buf ^ 1);
+                __syncthreads();
+            }
         }
     }
 
-    // ---- epilogue: bias + ReLU, store Cout channels at the view's channel offset --------------------------
-    float* __restrict__ out = a.out.p;
-    const int64_t opitch = a.out.sw;
+    // ---- epilogue ---------------------------------------------------------------------------------------
+    // nsplit == 1: bias + ReLU, store Cout channels at the view's channel offset.
+    // nsplit  > 1: raw partial sums to workspace slab [split][M][Cout]; splitk_reduce_kernel finishes the job.
+    const bool partial = nsplit > 1;
+    float* __restrict__ out = partial ? a.workspace + int64_t(split) * M * Cout : a.out.p;
+    const int opitch = partial ? Cout : int(a.out.sw);
+    // finish the values in place first, so the stores below issue back-to-back from distinct registers
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + (wn_i * TN + j) * 32 + r;
-        const bool nok = n < Cout;
-        const float bv = (a.bias != nullptr && nok) ? a.bias[n] : 0.f;
+        const float bv = (!partial && a.bias != nullptr && n < Cout) ? a.bias[n] : 0.f;
+        const bool do_relu = a.relu && !partial;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int mb = m0 + (wm_i * TM + i) * 32 + 4 * hh;
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = mb + (e & 3) + 8 * (e >> 2);
                 float v = acc[i][j][e] + bv;
-                if (a.relu) v = fmaxf(v, 0.f);
-                if (nok && m < M) out[int64_t(m) * opitch + n] = v;
+                acc[i][j][e] = do_relu ? fmaxf(v, 0.f) : v;
+            }
+    }
+    const bool full = (m0 + BM <= M) && (n0 + BN <= Cout);     // workgroup-uniform: interior tiles skip the guards
+    if (full) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn_i * TN + j) * 32 + r;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                float* o = out + int64_t(m0 + (wm_i * TM + i) * 32 + 4 * hh) * opitch + n;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[((e & 3) + 8 * (e >> 2)) * opitch] = acc[i][j][e];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn_i * TN + j) * 32 + r;
+            const bool nok = n < Cout;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int mb = m0 + (wm_i * TM + i) * 32 + 4 * hh;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = mb + (e & 3) + 8 * (e >> 2);
+                    if (nok && m < M) out[int64_t(m) * opitch + n] = acc[i][j][e];
+                }
             }
         }
     }
+}
+
+// Sum the split-K slabs, add bias, apply ReLU, write the NHWC view.  One thread per output element (n fastest).
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, const int nsplit, const int64_t M, const int Cout,
+                                     const float* __restrict__ bias, const int relu, float* __restrict__ out, const int64_t opitch) {
+    const int64_t idx = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int64_t total = M * Cout;
+    if (idx >= total) return;
+    const int n = int(idx % Cout);
+    const int64_t m = idx / Cout;
+    float v = bias ? bias[n] : 0.f;
+    for (int s = 0; s < nsplit; ++s) v += ws[int64_t(s) * total + idx];
+    if (relu) v = fmaxf(v, 0.f);
+    out[m * opitch + n] = v;
 }
 
 template <int T, bool VEC>
@@ -291,13 +358,18 @@ static size_t igemm_lds_bytes() {
 }
 
 template <int T, bool VEC>
-static hipError_t launch_igemm_t(const ConvArgs& a, hipStream_t stream) {
+static hipError_t launch_igemm_t(const ConvArgs& a, int splitk, hipStream_t stream) {
     constexpr IgemmTile t = kIgemmTiles[T];
     const int64_t M = int64_t(a.out.n) * a.out.h * a.out.w;
     const int tiles_m = int((M + t.bm - 1) / t.bm), tiles_n = (a.out.c + t.bn - 1) / t.bn;
     const int num_tiles = tiles_m * tiles_n;
     conv_igemm_kernel<t.bm, t.bn, t.wm, t.wn, VEC>
-        <<<dim3(num_tiles), dim3(64 * t.wm * t.wn), igemm_lds_bytes<T, VEC>(), stream>>>(a, tiles_n, num_tiles);
+        <<<dim3(num_tiles, splitk), dim3(64 * t.wm * t.wn), igemm_lds_bytes<T, VEC>(), stream>>>(a, tiles_n, num_tiles);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || splitk == 1) return e;
+    const int64_t total = M * a.out.c;
+    splitk_reduce_kernel<<<dim3(unsigned((total + 255) / 256)), dim3(256), 0, stream>>>(a.workspace, splitk, M, a.out.c, a.bias,
+                                                                                      a.relu, a.out.p, a.out.sw);
     return hipGetLastError();
 }
 
@@ -308,9 +380,14 @@ static hipError_t init_igemm_t() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, int(igemm_lds_bytes<T, VEC>()));
 }
 
-hipError_t LaunchConvIgemm(const ConvArgs& a, int tile, int vec, hipStream_t stream) {
+hipError_t LaunchConvIgemm(const ConvArgs& a, int tile, int vec, int splitk, hipStream_t stream) {
     if (a.out.sc != 1) return hipErrorInvalidValue;
+    if (splitk < 1 || splitk > 64 || (splitk > 1 && a.workspace == nullptr)) return hipErrorInvalidValue;
     if (int64_t(a.out.n) * a.out.h * a.out.w >= (int64_t(1) << 31)) return hipErrorInvalidValue;
+    // 32-bit element offsets inside the kernels
+    if (int64_t(a.in.n) * a.in.sn >= (int64_t(1) << 31) || int64_t(a.out.c) * a.kh * a.kw * a.in.c >= (int64_t(1) << 31) ||
+        int64_t(a.out.n) * a.out.h * a.out.w * a.out.sw >= (int64_t(1) << 31))
+        return hipErrorInvalidValue;
     if (vec) {
         if (a.in.sc != 1 || (a.in.c & 3) || (a.in.sw & 3) || (a.in.sh & 3) || (a.in.sn & 3) ||
             (reinterpret_cast<uintptr_t>(a.in.p) & 15) || (reinterpret_cast<uintptr_t>(a.w) & 15))
@@ -319,7 +396,7 @@ hipError_t LaunchConvIgemm(const ConvArgs& a, int tile, int vec, hipStream_t str
             return hipErrorInvalidValue;
     }
 #define IE_CASE(T)                                                                                  \
-    case T: return vec ? launch_igemm_t<T, true>(a, stream) : launch_igemm_t<T, false>(a, stream);
+    case T: return vec ? launch_igemm_t<T, true>(a, splitk, stream) : launch_igemm_t<T, false>(a, splitk, stream);
     switch (tile) {
         IE_CASE(0) IE_CASE(1) IE_CASE(2) IE_CASE(3) IE_CASE(4) IE_CASE(5) IE_CASE(6)
         default: return hipErrorInvalidValue;

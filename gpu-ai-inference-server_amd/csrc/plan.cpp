@@ -703,6 +703,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                 else if (K <= 2048) s.algo = ConvAlgo::IgemmScalar;
                 else s.algo = ConvAlgo::Naive;
                 s.tile = choose_tile(M, N);
+                s.splitk = 1;
                 // Test / tuning overrides (read at plan time): IE_FORCE_TILE=<0..6>, IE_FORCE_ALGO=naive|scalar
                 if (const char* ft = std::getenv("IE_FORCE_TILE")) {
                     int t = std::atoi(ft);
@@ -713,6 +714,23 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                     if (f == "naive") s.algo = ConvAlgo::Naive;
                     else if (f == "scalar" && K <= 2048) s.algo = ConvAlgo::IgemmScalar;
                     else if (f == "igemm" && s.algo == ConvAlgo::Naive) s.algo = vec_ok ? ConvAlgo::IgemmVec : (K <= 2048 ? ConvAlgo::IgemmScalar : ConvAlgo::Naive);
+                }
+                if (s.algo != ConvAlgo::Naive) {
+                    // split-K when the output grid cannot fill the chip: aim for >= ~768 workgroups, keep >= 2 K-tiles
+                    // per split.  (Deterministic two-pass reduction, see kernels.hip.)
+                    const IgemmTile& T = kIgemmTiles[s.tile];
+                    const int64_t wgs = ((M + T.bm - 1) / T.bm) * ((N + T.bn - 1) / T.bn);
+                    const int64_t cblocks = (s.in.c + kIgemmBK - 1) / kIgemmBK;
+                    const int64_t KT = s.algo == ConvAlgo::IgemmVec ? int64_t(n.kh) * n.kw * cblocks : (K + kIgemmBK - 1) / kIgemmBK;
+                    if (wgs < 384 && KT >= 4) {
+                        int64_t want = (768 + wgs - 1) / wgs;
+                        s.splitk = int(std::max<int64_t>(1, std::min<int64_t>({want, KT / 2, 32})));
+                    }
+                    if (const char* fs = std::getenv("IE_FORCE_SPLITK")) {
+                        int v = std::atoi(fs);
+                        if (v >= 1 && v <= 64) s.splitk = v;
+                    }
+                    if (s.splitk > 1) plan.workspace_floats = std::max<int64_t>(plan.workspace_floats, int64_t(s.splitk) * M * N);
                 }
                 break;
             }
@@ -820,7 +838,7 @@ std::string PlanToJson(const Plan& p) {
     }
     o << "],\"buffers\":[";
     for (size_t i = 0; i < p.buffer_floats.size(); ++i) o << (i ? "," : "") << p.buffer_floats[i];
-    o << "],\"weight_floats\":" << p.weights.size() << ",\"total_flops\":" << p.total_flops
+    o << "],\"workspace_floats\":" << p.workspace_floats << ",\"weight_floats\":" << p.weights.size() << ",\"total_flops\":" << p.total_flops
       << ",\"total_bytes\":" << p.total_bytes << ",\"steps\":[";
     for (size_t i = 0; i < p.steps.size(); ++i) {
         const Step& s = p.steps[i];
@@ -832,7 +850,7 @@ std::string PlanToJson(const Plan& p) {
           << s.pl << "," << s.pb << "," << s.pr << "]";
         o << ",\"pre\":" << (s.pre_scale_off >= 0 ? "true" : "false") << ",\"pre_relu\":" << (s.pre_relu ? "true" : "false")
           << ",\"relu\":" << (s.relu ? "true" : "false") << ",\"bias\":" << (s.bias_off >= 0 ? "true" : "false");
-        if (s.kind == StepKind::Conv) o << ",\"algo\":\"" << algos[int(s.algo)] << "\",\"tile\":" << s.tile;
+        if (s.kind == StepKind::Conv) o << ",\"algo\":\"" << algos[int(s.algo)] << "\",\"tile\":" << s.tile << ",\"splitk\":" << s.splitk;
         if (s.kind == StepKind::Pool) o << ",\"max\":" << (s.pool_max ? "true" : "false");
         o << ",\"flops\":" << s.flops << ",\"bytes\":" << s.bytes << "}";
     }

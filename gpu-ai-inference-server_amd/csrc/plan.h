@@ -52,7 +52,8 @@ struct Step {
     bool pre_relu = false;
     bool relu = false;         // applied to the result
     ConvAlgo algo = ConvAlgo::Naive;
-    int tile = 0;              // igemm tile configuration index (see kernels.h)
+    int tile = 0;              // igemm tile configuration index (see igemm_tiles.h)
+    int splitk = 1;            // >1: K-tiles split over this many workgroups per output tile (+ reduce kernel)
     double flops = 0;          // algorithmic FLOPs (2*MACs) of this step for the planned shape
     double bytes = 0;          // algorithmic bytes: operands read once + result written once
 };
@@ -70,6 +71,7 @@ struct Plan {
     std::vector<int64_t> buffer_floats;   // size of each device activation buffer
     std::vector<Step> steps;
     std::vector<float> weights;           // packed blob (batch independent)
+    int64_t workspace_floats = 0;         // split-K partial-sum slabs (max over steps of splitk*M*Cout)
     double total_flops = 0, total_bytes = 0;
     int64_t activation_floats() const { int64_t s = 0; for (auto b : buffer_floats) s += b; return s; }
 };

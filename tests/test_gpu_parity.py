@@ -154,6 +154,32 @@ def test_every_igemm_tile_and_loader(model_repo, tile, algo):
         del os.environ["IE_FORCE_TILE"], os.environ["IE_FORCE_ALGO"]
 
 
+@pytest.mark.parametrize("splitk", [2, 3, 7])
+def test_split_k_reduction(model_repo, splitk):
+    """K-tiles split over several workgroups + deterministic slab reduction (bias/ReLU applied after the sum)."""
+    os.environ["IE_FORCE_SPLITK"] = str(splitk)
+    os.environ["IE_FORCE_ALGO"] = "igemm"
+    try:
+        for name, tile in (("mini_densenet_scale", 5), ("mini_resnet_block", 4), ("mini_gemm_mlp", 3)):
+            os.environ["IE_FORCE_TILE"] = str(tile)
+            mk, iname, ishape = MINI[name]
+            om = O.load_model(mk(models))
+            oname, oshape, _ = om.outputs[0]
+            x = models.synthetic_input(ishape, stream=name)
+            ref64 = np.load(os.path.join(GOLD, name + ".npz"))["output_f64"]
+            m = B.CreateModel(os.path.join(model_repo, name, "1"), name)
+            try:
+                y, _ = infer(m, "", iname, x, oname, oshape)
+                y2, _ = infer(m, "", iname, x, oname, oshape)
+                assert rel_err(y, ref64) < RTOL, (name, splitk, rel_err(y, ref64))
+                np.testing.assert_array_equal(y, y2)          # no atomics: bitwise reproducible
+            finally:
+                m.Destroy()
+    finally:
+        for k in ("IE_FORCE_SPLITK", "IE_FORCE_ALGO", "IE_FORCE_TILE"):
+            os.environ.pop(k, None)
+
+
 def test_naive_kernel_agrees(model_repo):
     os.environ["IE_FORCE_ALGO"] = "naive"
     try:
