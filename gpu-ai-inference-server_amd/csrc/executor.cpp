@@ -30,6 +30,7 @@ TensorArg make_arg(const PlanInstance& pi, const View& v) {
 }
 
 constexpr size_t kChunk = size_t(4) << 20;   // pinned staging chunk
+constexpr int64_t kTuneWorkspaceFloats = int64_t(16) << 20;   // 64 MiB of split-K slabs available to the autotuner
 constexpr int kSlots = 4;
 
 std::once_flag g_kernels_once;
@@ -72,6 +73,8 @@ DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id) 
     check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
     const char* ng = std::getenv("IE_DISABLE_GRAPH");
     use_graph_ = !(ng && ng[0] == '1');
+    const char* at = std::getenv("IE_AUTOTUNE");
+    autotune_ = !(at && at[0] == '0') && !std::getenv("IE_FORCE_TILE") && !std::getenv("IE_FORCE_SPLITK") && !std::getenv("IE_FORCE_ALGO");
     pinned_bytes_ = kChunk * kSlots;
     check(hipHostMalloc(&pinned_, pinned_bytes_, hipHostMallocDefault), "hipHostMalloc");
 }
@@ -116,12 +119,14 @@ PlanInstance& DeviceModel::Prepare(const std::vector<std::vector<int64_t>>& shap
         device_bytes_ += bytes;
         pi->buffers.push_back(p);
     }
+    if (autotune_) pi->plan.workspace_floats = std::max<int64_t>(pi->plan.workspace_floats, kTuneWorkspaceFloats);
     if (pi->plan.workspace_floats > 0) {
         size_t bytes = size_t(pi->plan.workspace_floats) * sizeof(float);
         check(hipMalloc(reinterpret_cast<void**>(&pi->workspace), bytes), "hipMalloc(workspace)");
         device_bytes_ += bytes;
     }
     check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+    if (autotune_) Autotune(*pi);
 
     if (use_graph_) {
         hipGraph_t graph = nullptr;
@@ -142,6 +147,55 @@ PlanInstance& DeviceModel::Prepare(const std::vector<std::vector<int64_t>>& shap
     current_ = pi.get();
     plans_[key] = std::move(pi);
     return *current_;
+}
+
+void DeviceModel::Autotune(PlanInstance& pi) {
+    hipEvent_t e0, e1;
+    check(hipEventCreate(&e0), "hipEventCreate");
+    check(hipEventCreate(&e1), "hipEventCreate");
+    static const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24};
+    try {
+        for (Step& s : pi.plan.steps) {
+            if (s.kind != StepKind::Conv || s.algo == ConvAlgo::Naive) continue;
+            const int64_t M = s.out.n * s.out.h * s.out.w, N = s.out.c;
+            const int64_t KT = s.algo == ConvAlgo::IgemmVec ? int64_t(s.kh) * s.kw * ((s.in.c + kIgemmBK - 1) / kIgemmBK)
+                                                           : (int64_t(s.kh) * s.kw * s.in.c + kIgemmBK - 1) / kIgemmBK;
+            std::vector<int64_t> key = {M, N, s.in.c, s.kh, s.kw, s.sh, s.sw, s.pt, s.pl, s.in.h, s.in.w, s.in.pitch, s.out.pitch,
+                                        s.in.nchw, int64_t(s.algo), s.pre_scale_off >= 0, s.bias_off >= 0};
+            auto hit = tune_cache_.find(key);
+            if (hit != tune_cache_.end()) { s.tile = hit->second.first; s.splitk = hit->second.second; continue; }
+            float best = 1e30f;
+            int best_tile = s.tile, best_split = s.splitk;
+            for (int t = 0; t < kNumIgemmTiles; ++t) {
+                const IgemmTile& T = kIgemmTiles[t];
+                if ((T.bn > 32 && N <= 32) || (T.bn > 64 && N <= 64)) continue;
+                const int64_t wgs = ((M + T.bm - 1) / T.bm) * ((N + T.bn - 1) / T.bn);
+                for (int sp : kSplits) {
+                    if (sp > 1 && (KT / sp < 2 || int64_t(sp) * M * N > pi.plan.workspace_floats || wgs * sp > 8192 || wgs >= 1024)) continue;
+                    Step trial = s;
+                    trial.tile = t;
+                    trial.splitk = sp;
+                    LaunchStep(pi, trial);                       // warm
+                    check(hipEventRecord(e0, stream_), "hipEventRecord");
+                    for (int r = 0; r < 3; ++r) LaunchStep(pi, trial);
+                    check(hipEventRecord(e1, stream_), "hipEventRecord");
+                    check(hipEventSynchronize(e1), "hipEventSynchronize");
+                    float ms = 0;
+                    check(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime");
+                    if (ms < best) { best = ms; best_tile = t; best_split = sp; }
+                }
+            }
+            s.tile = best_tile;
+            s.splitk = best_split;
+            tune_cache_[key] = {best_tile, best_split};
+        }
+    } catch (...) {
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        throw;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
 }
 
 void DeviceModel::LaunchStep(const PlanInstance& pi, const Step& s) {

@@ -61,6 +61,9 @@ public:
 
 private:
     void RunSteps(PlanInstance& pi, std::vector<StepTiming>* timings, std::vector<hipEvent_t>* events);
+    // Exhaustive (tile, split-K) search per distinct conv shape, timed with HIP events on the model's stream; the
+    // MI355X counterpart of the reference's cudnn_conv_algo_search = Exhaustive (model.cpp:886).
+    void Autotune(PlanInstance& pi);
     void LaunchStep(const PlanInstance& pi, const Step& s);
 
     std::shared_ptr<const OnnxModel> model_;
@@ -70,6 +73,8 @@ private:
     size_t weight_floats_ = 0;
     size_t device_bytes_ = 0;
     bool use_graph_ = true;
+    bool autotune_ = true;
+    std::map<std::vector<int64_t>, std::pair<int, int>> tune_cache_;   // conv signature -> (tile, splitk)
     std::map<std::vector<int64_t>, std::unique_ptr<PlanInstance>> plans_;
     PlanInstance* current_ = nullptr;
     void* pinned_ = nullptr;           // pinned host staging ring for H2D/D2H
