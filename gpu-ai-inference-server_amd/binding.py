@@ -69,7 +69,7 @@ ABI_SYMBOLS = [
     "ModelLoad", "ModelUnload",
 ]
 EXT_SYMBOLS = ["EngineDescribeModel", "EnginePrepare", "EngineRunPrepared", "EngineSynchronize", "EngineGetStream",
-               "EngineProfile", "EngineGetWeightBlob", "EngineMemcpy", "EngineVectorAdd"]
+               "EngineProfile", "EngineGetWeightBlob", "EngineMemcpy", "EngineMfmaPeak", "EngineVectorAdd"]
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -112,6 +112,7 @@ def lib() -> C.CDLL:
             "EngineGetWeightBlob": (C.c_bool, [vp, ep, C.POINTER(C.c_size_t), ep]),
             "EngineVectorAdd": (C.c_bool, [vp, vp, vp, C.c_size_t, ep]),
             "EngineMemcpy": (C.c_bool, [vp, vp, vp, C.c_size_t, C.c_int, ep]),
+            "EngineMfmaPeak": (C.c_double, [C.c_int, C.c_int, C.c_int]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)   # AttributeError here = symbol missing from the .so
@@ -505,6 +506,10 @@ def CopyToHost(model: Model, dst: np.ndarray, src_dev: int) -> None:
     err = C.c_void_p()
     if not lib().EngineMemcpy(model.handle, dst.ctypes.data, src_dev, dst.nbytes, 2, C.byref(err)):
         raise RuntimeError(_take_error(err))
+
+
+def MfmaPeak(nacc: int = 4, blocks_per_cu: int = 1, iters: int = 2000) -> float:
+    return float(lib().EngineMfmaPeak(nacc, blocks_per_cu, iters))
 
 
 def VectorAdd(a: np.ndarray, b: np.ndarray) -> np.ndarray:

@@ -612,6 +612,11 @@ bool EngineMemcpy(ModelHandle handle, void* dst, const void* src, size_t bytes, 
     catch (...) { set_error(error, "unknown error"); return false; }
 }
 
+double EngineMfmaPeak(int nacc, int blocks_per_cu, int iters) {
+    if (ie::HipDeviceCount() <= 0) return -1.0;
+    try { return ie::MfmaPeakTflops(nacc, blocks_per_cu, iters); } catch (...) { return -1.0; }
+}
+
 bool EngineVectorAdd(const float* a, const float* b, float* result, size_t n, ErrorMessage* error) {
     if (!a || !b || !result) { set_error(error, "Invalid parameters"); return false; }
     if (ie::HipDeviceCount() <= 0) { set_error(error, "No HIP device available"); return false; }

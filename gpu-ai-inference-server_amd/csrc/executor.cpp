@@ -3,6 +3,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
+#include <sstream>
 #include <stdexcept>
 
 #include "igemm_tiles.h"
@@ -75,6 +77,19 @@ DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id) 
     use_graph_ = !(ng && ng[0] == '1');
     const char* at = std::getenv("IE_AUTOTUNE");
     autotune_ = !(at && at[0] == '0') && !std::getenv("IE_FORCE_TILE") && !std::getenv("IE_FORCE_SPLITK") && !std::getenv("IE_FORCE_ALGO");
+    // Optional persistent tuning cache (IE_TUNE_CACHE=<file>): "<17 signature ints> : <tile> <splitk>" per line.
+    if (const char* tc = std::getenv("IE_TUNE_CACHE")) {
+        std::ifstream f(tc);
+        std::string line;
+        while (std::getline(f, line)) {
+            std::istringstream is(line);
+            std::vector<int64_t> key;
+            std::string tok;
+            while (is >> tok && tok != ":") key.push_back(std::stoll(tok));
+            int t = -1, sp = 0;
+            if ((is >> t >> sp) && t >= 0 && t < kNumIgemmTiles && sp >= 1 && sp <= 64) tune_cache_[key] = {t, sp};
+        }
+    }
     pinned_bytes_ = kChunk * kSlots;
     check(hipHostMalloc(&pinned_, pinned_bytes_, hipHostMallocDefault), "hipHostMalloc");
 }
@@ -196,6 +211,13 @@ void DeviceModel::Autotune(PlanInstance& pi) {
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    if (const char* tc = std::getenv("IE_TUNE_CACHE")) {
+        std::ofstream f(tc, std::ios::trunc);
+        for (auto& kv : tune_cache_) {
+            for (auto v : kv.first) f << v << ' ';
+            f << ": " << kv.second.first << ' ' << kv.second.second << '\n';
+        }
+    }
 }
 
 void DeviceModel::LaunchStep(const PlanInstance& pi, const Step& s) {

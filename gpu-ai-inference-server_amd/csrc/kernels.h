@@ -24,6 +24,8 @@ struct ConvArgs {
     int kh = 1, kw = 1, sh = 1, sw = 1, pt = 0, pl = 0;
     int pre_relu = 0, relu = 0;
     float* workspace = nullptr;        // split-K partial slabs [splitk][M][Cout] (only when splitk > 1)
+    int debug = 0;                     // timing-only ablation bits (IE_DEBUG_ABLATE), 0 in production
+    int64_t in_bytes = 0;              // filled by LaunchConvIgemm: byte span of the input view (buffer descriptor range)
 };
 
 struct PoolArgs {
@@ -52,6 +54,9 @@ hipError_t LaunchEltwise(const EltArgs& a, hipStream_t stream);
 hipError_t LaunchCopy(const TensorArg& in, const TensorArg& out, hipStream_t stream);
 // result[i] = a[i] + b[i]  (the reference's only authored kernel: cuda_utils.cu:10-15)
 hipError_t LaunchVectorAdd(const float* a, const float* b, float* result, int64_t n, hipStream_t stream);
+
+// Calibration: achievable fp32 MFMA rate of this device (register-resident loop, no memory traffic).
+double MfmaPeakTflops(int nacc, int blocks_per_cu, int iters);
 
 // One-time per-process setup (raises the dynamic-LDS limit of the igemm kernels).
 hipError_t InitKernels();

@@ -20,6 +20,8 @@
 //   pool / gap / eltwise / copy: bandwidth-bound NHWC kernels, 16 B per lane where alignment allows.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "igemm_tiles.h"
 #include "kernels.h"
 
@@ -31,7 +33,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------------------------------
 // implicit-GEMM convolution on v_mfma_f32_32x32x2_f32
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool VEC>
+template <int BM, int BN, int WM, int WN, bool VEC, bool PRE>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs a, const int tiles_n, const int num_tiles) {
     constexpr int NT = 64 * WM * WN;
     constexpr int BK = kIgemmBK;
@@ -103,6 +105,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
 
     if constexpr (VEC) {
         // ---- float4 staging: thread owns column-quad `c4` of rows {rw + i*ROWS_PER_PASS} ----------------
+        // The per-K-tile VALU work is kept to a few instructions per row (it competes with the MFMAs of the
+        // co-resident waves for issue slots): all per-row geometry is folded ONCE into a 32-bit element offset of
+        // the window's top-left tap plus a bit mask of the taps that fall inside the image; per K-tile a row costs one
+        // add, one bit test and one select.  Loads are buffer loads: a masked-off lane gets an out-of-range offset and
+        // the hardware returns zeros, which IS the conv zero padding when there is no activation prologue.
         constexpr int ROWS_PER_PASS = NT / 8;
         constexpr int A_IT = BM / ROWS_PER_PASS, B_IT = BN / ROWS_PER_PASS;
         static_assert(A_IT >= 1 && B_IT >= 1, "tile too small for the thread count");
@@ -111,10 +118,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
         const int cblocks = (Cin + BK - 1) / BK;
         const int KT = a.kh * a.kw * cblocks;
         const int kt_begin = int(int64_t(KT) * split / nsplit), kt_end = int(int64_t(KT) * (split + 1) / nsplit);
+        const int ish = int(a.in.sh), isw = int(a.in.sw);
+        constexpr unsigned OOB = 0x80000000u;    // >= num_records of every descriptor (views are < 2^31 bytes)
 
-        // All element offsets fit 32 bits (LaunchConvIgemm rejects views of >= 2^31 floats).
-        const int isn = int(a.in.sn), ish = int(a.in.sh), isw = int(a.in.sw);
-        int iy0[A_IT], ix0[A_IT], rbase[A_IT];
+        const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(in), 0, int(a.in_bytes), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(wgt), 0, Cout * Ktot * 4, 0x00020000);
+
+        int poff[A_IT];                  // element offset of tap (0,0), channel c4 of this row's window
+        unsigned taps[A_IT];             // bit t set: tap t of this row lies inside the image (kh*kw <= 32)
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int m = m0 + rw + i * ROWS_PER_PASS;
@@ -123,66 +136,65 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
             const int b = mm / (OH * OW);
             const int rem = mm - b * (OH * OW);
             const int oy = rem / OW, ox = rem - oy * OW;
-            iy0[i] = mok ? oy * a.sh - a.pt : -(1 << 28);    // every tap of a tail row falls outside -> zeros
-            ix0[i] = ox * a.sw - a.pl;
-            rbase[i] = b * isn;
+            const int iy0 = oy * a.sh - a.pt, ix0 = ox * a.sw - a.pl;
+            poff[i] = b * int(a.in.sn) + iy0 * ish + ix0 * isw + c4;
+            unsigned msk = 0;
+            for (int ky = 0; ky < a.kh; ++ky)
+                for (int kx = 0; kx < a.kw; ++kx)
+                    if (unsigned(iy0 + ky) < unsigned(H) && unsigned(ix0 + kx) < unsigned(W)) msk |= 1u << (ky * a.kw + kx);
+            taps[i] = mok ? msk : 0u;
         }
+        int boff[B_IT];                  // element offset of (row n, k = c4) in the packed weights
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) boff[i] = (n0 + rw + i * ROWS_PER_PASS) * Ktot + c4;   // rows >= Cout land out of range
+
         f32x4 ra[A_IT], rb[B_IT];
         f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
-        unsigned okmask = 0;     // bit i: A row i valid, bit 16+i: B row i valid
-        // Phase 1: issue the global loads of K-tile kt (raw values; nothing here depends on their arrival).
+        unsigned okmask = 0;
+        // Phase 1: issue the loads of K-tile kt (raw values; nothing here depends on their arrival).
         auto issue_loads = [&](int kt) {
             const int tap = kt / cblocks;
-            const int c = (kt - tap * cblocks) * BK + c4;
+            const int c0 = (kt - tap * cblocks) * BK;
             const int ky = tap / a.kw, kx = tap - ky * a.kw;
-            const bool cok = c < Cin;
-            okmask = 0;
-            if (has_pre) {
-                const int cc = cok ? c : 0;
+            const int tapoff = ky * ish + kx * isw + c0;          // scalar
+            const int woff = tap * Cin + c0;                      // scalar
+            const bool cok = c0 + c4 < Cin;
+            if constexpr (PRE) {
+                const int cc = cok ? c0 + c4 : 0;
                 s4 = *reinterpret_cast<const f32x4*>(a.pre_scale + cc);
                 t4 = *reinterpret_cast<const f32x4*>(a.pre_shift + cc);
+                okmask = 0;
             }
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
-                const int iy = iy0[i] + ky, ix = ix0[i] + kx;
-                const bool ok = cok && unsigned(iy) < unsigned(H) && unsigned(ix) < unsigned(W);
-                okmask |= ok ? (1u << i) : 0u;
-                // unconditional load from a clamped address: keeps all loads of the tile in flight together
-                int off = rbase[i] + iy * ish + ix * isw + c;
-                off = ok ? off : 0;
-                ra[i] = *reinterpret_cast<const f32x4*>(in + off);
+                const bool ok = cok && ((taps[i] >> tap) & 1u);
+                const unsigned off = ok ? unsigned(poff[i] + tapoff) * 4u : OOB;
+                ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0));
+                if constexpr (PRE) okmask |= ok ? (1u << i) : 0u;
             }
 #pragma unroll
             for (int i = 0; i < B_IT; ++i) {
-                const int n = n0 + rw + i * ROWS_PER_PASS;
-                const bool bok = cok && n < Cout;
-                okmask |= bok ? (1u << (16 + i)) : 0u;
-                int off = n * Ktot + tap * Cin + c;
-                off = bok ? off : 0;
-                rb[i] = *reinterpret_cast<const f32x4*>(wgt + off);
+                const unsigned off = cok ? unsigned(boff[i] + woff) * 4u : OOB;
+                rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0));
             }
         };
-        // Phase 3 (after the MFMAs of the previous tile): activation prologue, zero padding, LDS store.
+        // Phase 3 (after the MFMAs of the previous tile): activation prologue (+ re-zeroing of padded lanes), LDS store.
         auto finish_store = [&](int buf) {
-            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
                 f32x4 v = ra[i];
-                if (has_pre) {
+                if constexpr (PRE) {
                     v = v * s4 + t4;
                     if (a.pre_relu) {
                         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                     }
+                    if (!(okmask & (1u << i))) v = f32x4{0.f, 0.f, 0.f, 0.f};   // zero padding applies AFTER the activation
                 }
-                if (!(okmask & (1u << i))) v = zero;      // zero padding is applied AFTER the activation
                 *reinterpret_cast<f32x4*>(sA + buf * BM * LDP + (rw + i * ROWS_PER_PASS) * LDP + c4) = v;
             }
 #pragma unroll
-            for (int i = 0; i < B_IT; ++i) {
-                f32x4 v = rb[i];
-                if (!(okmask & (1u << (16 + i)))) v = zero;
-                *reinterpret_cast<f32x4*>(sB + buf * BN * LDP + (rw + i * ROWS_PER_PASS) * LDP + c4) = v;
-            }
+            for (int i = 0; i < B_IT; ++i)
+                *reinterpret_cast<f32x4*>(sB + buf * BN * LDP + (rw + i * ROWS_PER_PASS) * LDP + c4) = rb[i];
         };
 
         if (kt_begin < kt_end) {
@@ -192,12 +204,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
             for (int kt = kt_begin; kt < kt_end; ++kt) {
                 const int buf = (kt - kt_begin) & 1;
                 const bool more = kt + 1 < kt_end;
-                if (more) issue_loads(kt + 1);
+                if (more && !(a.debug & 1)) issue_loads(kt + 1);
                 __builtin_amdgcn_sched_barrier(0);       // loads stay ahead of the MFMA block ...
-                compute(buf);
+                if (!(a.debug & 2)) compute(buf);
                 __builtin_amdgcn_sched_barrier(0);       // ... and their consumers stay behind it
-                if (more) finish_store(buf ^ 1);
-                __syncthreads();
+                if (more && !(a.debug & 4)) finish_store(buf ^ 1);
+                if (!(a.debug & 8)) __syncthreads();
             }
         }
     } else {
@@ -357,13 +369,13 @@ static size_t igemm_lds_bytes() {
     return b;
 }
 
-template <int T, bool VEC>
+template <int T, bool VEC, bool PRE>
 static hipError_t launch_igemm_t(const ConvArgs& a, int splitk, hipStream_t stream) {
     constexpr IgemmTile t = kIgemmTiles[T];
     const int64_t M = int64_t(a.out.n) * a.out.h * a.out.w;
     const int tiles_m = int((M + t.bm - 1) / t.bm), tiles_n = (a.out.c + t.bn - 1) / t.bn;
     const int num_tiles = tiles_m * tiles_n;
-    conv_igemm_kernel<t.bm, t.bn, t.wm, t.wn, VEC>
+    conv_igemm_kernel<t.bm, t.bn, t.wm, t.wn, VEC, PRE>
         <<<dim3(num_tiles, splitk), dim3(64 * t.wm * t.wn), igemm_lds_bytes<T, VEC>(), stream>>>(a, tiles_n, num_tiles);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || splitk == 1) return e;
@@ -373,15 +385,22 @@ static hipError_t launch_igemm_t(const ConvArgs& a, int splitk, hipStream_t stre
     return hipGetLastError();
 }
 
-template <int T, bool VEC>
+template <int T, bool VEC, bool PRE>
 static hipError_t init_igemm_t() {
     constexpr IgemmTile t = kIgemmTiles[T];
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<t.bm, t.bn, t.wm, t.wn, VEC>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<t.bm, t.bn, t.wm, t.wn, VEC, PRE>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, int(igemm_lds_bytes<T, VEC>()));
 }
 
-hipError_t LaunchConvIgemm(const ConvArgs& a, int tile, int vec, int splitk, hipStream_t stream) {
+hipError_t LaunchConvIgemm(const ConvArgs& a_in, int tile, int vec, int splitk, hipStream_t stream) {
+    ConvArgs a = a_in;
+    static const int dbg = [] { const char* e = std::getenv("IE_DEBUG_ABLATE"); return e ? std::atoi(e) : 0; }();
+    a.debug = dbg;   // timing-only ablations (wrong results): 1 no loads, 2 no MFMA, 4 no LDS stores, 8 no barrier
     if (a.out.sc != 1) return hipErrorInvalidValue;
+    // bytes from in.p to one past the last element of the view: the range of the kernel's buffer descriptor
+    a.in_bytes = 4 * (int64_t(a.in.n - 1) * a.in.sn + int64_t(a.in.h - 1) * a.in.sh + int64_t(a.in.w - 1) * a.in.sw + int64_t(a.in.c - 1) * a.in.sc + 1);
+    if (vec && (a.in_bytes >= (int64_t(1) << 31) || int64_t(a.out.c) * a.kh * a.kw * a.in.c * 4 >= (int64_t(1) << 31) || a.kh * a.kw > 32))
+        return hipErrorInvalidValue;
     if (splitk < 1 || splitk > 64 || (splitk > 1 && a.workspace == nullptr)) return hipErrorInvalidValue;
     if (int64_t(a.out.n) * a.out.h * a.out.w >= (int64_t(1) << 31)) return hipErrorInvalidValue;
     // 32-bit element offsets inside the kernels
@@ -396,7 +415,9 @@ hipError_t LaunchConvIgemm(const ConvArgs& a, int tile, int vec, int splitk, hip
             return hipErrorInvalidValue;
     }
 #define IE_CASE(T)                                                                                  \
-    case T: return vec ? launch_igemm_t<T, true>(a, splitk, stream) : launch_igemm_t<T, false>(a, splitk, stream);
+    case T:                                                                                          \
+        if (!vec) return launch_igemm_t<T, false, false>(a, splitk, stream);                        \
+        return a.pre_scale ? launch_igemm_t<T, true, true>(a, splitk, stream) : launch_igemm_t<T, true, false>(a, splitk, stream);
     switch (tile) {
         IE_CASE(0) IE_CASE(1) IE_CASE(2) IE_CASE(3) IE_CASE(4) IE_CASE(5) IE_CASE(6)
         default: return hipErrorInvalidValue;
@@ -407,8 +428,9 @@ hipError_t LaunchConvIgemm(const ConvArgs& a, int tile, int vec, int splitk, hip
 hipError_t InitKernels() {
     hipError_t e;
 #define IE_INIT(T)                                                     \
-    if ((e = init_igemm_t<T, true>()) != hipSuccess) return e;         \
-    if ((e = init_igemm_t<T, false>()) != hipSuccess) return e;
+    if ((e = init_igemm_t<T, true, true>()) != hipSuccess) return e;   \
+    if ((e = init_igemm_t<T, true, false>()) != hipSuccess) return e;  \
+    if ((e = init_igemm_t<T, false, false>()) != hipSuccess) return e;
     IE_INIT(0) IE_INIT(1) IE_INIT(2) IE_INIT(3) IE_INIT(4) IE_INIT(5) IE_INIT(6)
 #undef IE_INIT
     return hipSuccess;
@@ -621,6 +643,62 @@ hipError_t LaunchCopy(const TensorArg& in, const TensorArg& out, hipStream_t str
 __global__ void vector_add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ r, const int64_t n) {
     const int64_t stride = int64_t(gridDim.x) * blockDim.x;
     for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) r[i] = a[i] + b[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// calibration microbenchmark: register-resident v_mfma_f32_32x32x2_f32 loop (no memory traffic) with NACC
+// independent accumulator chains per wave; gives the device's achievable fp32 MFMA rate for roofline fractions.
+// ------------------------------------------------------------------------------------------------
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters) {
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = float(threadIdx.x + i + e) * 1e-3f;
+    float av = 1.0f + 1e-6f * float(threadIdx.x), bv = 0.999f - 1e-6f * float(threadIdx.x & 31);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += acc[i][e];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// returns TFLOP/s (<= 0 on error); blocks_per_cu x 4 waves per CU
+double MfmaPeakTflops(int nacc, int blocks_per_cu, int iters) {
+    float* d = nullptr;
+    const int blocks = 256 * blocks_per_cu;
+    if (hipMalloc(reinterpret_cast<void**>(&d), size_t(blocks) * 256 * 4) != hipSuccess) return -1;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    auto launch = [&] {
+        switch (nacc) {
+            case 1: mfma_peak_kernel<1><<<blocks, 256>>>(d, iters); break;
+            case 2: mfma_peak_kernel<2><<<blocks, 256>>>(d, iters); break;
+            default: mfma_peak_kernel<4><<<blocks, 256>>>(d, iters); break;
+        }
+    };
+    launch();
+    (void)hipEventRecord(e0, nullptr);
+    launch();
+    (void)hipEventRecord(e1, nullptr);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(d);
+    const int na = nacc == 1 ? 1 : (nacc == 2 ? 2 : 4);
+    const double flops = double(blocks) * 4.0 * double(iters) * 8.0 * na * (2.0 * 32 * 32 * 2);
+    return flops / (double(ms) * 1e-3) / 1e12;
 }
 
 hipError_t LaunchVectorAdd(const float* a, const float* b, float* result, int64_t n, hipStream_t stream) {

@@ -697,7 +697,8 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                 int64_t M = s.out.n * s.out.h * s.out.w, N = s.out.c, K = int64_t(n.kh) * n.kw * s.in.c;
                 s.flops = 2.0 * double(M) * double(N) * double(K);
                 s.bytes = 4.0 * (double(s.in.numel()) + double(s.out.numel()) + double(n.w.size()));
-                bool vec_ok = !s.in.nchw && s.in.c % 4 == 0 && s.in.pitch % 4 == 0 && s.in.c_off % 4 == 0;
+                bool vec_ok = !s.in.nchw && s.in.c % 4 == 0 && s.in.pitch % 4 == 0 && s.in.c_off % 4 == 0 && n.kh * n.kw <= 32 &&
+                              s.in.n * s.in.h * s.in.w * s.in.pitch * 4 < (int64_t(1) << 31) && int64_t(n.w.size()) * 4 < (int64_t(1) << 31);
                 if (M * N < 2048 && K <= 4096) s.algo = ConvAlgo::Naive;
                 else if (vec_ok) s.algo = ConvAlgo::IgemmVec;
                 else if (K <= 2048) s.algo = ConvAlgo::IgemmScalar;

@@ -37,6 +37,9 @@ bool EngineGetWeightBlob(ModelHandle handle, void** d_ptr, size_t* bytes, ErrorM
 /* Synchronous hipMemcpy on the model's device: kind 1 = host->device, 2 = device->host, 3 = device->device.
  * Lets a test or benchmark fill / read the engine-owned buffers returned by EnginePrepare. */
 bool EngineMemcpy(ModelHandle handle, void* dst, const void* src, size_t bytes, int kind, ErrorMessage* error);
+/* Calibration microbenchmark: TFLOP/s of a register-resident v_mfma_f32_32x32x2_f32 loop with `nacc` (1, 2 or 4)
+ * independent accumulator chains per wave and `blocks_per_cu` 4-wave workgroups per CU; <= 0 on error. */
+double EngineMfmaPeak(int nacc, int blocks_per_cu, int iters);
 /* result = a + b on the GPU for host arrays (the reference's VectorAdd smoke test, cuda_utils.cu:59-149). */
 bool EngineVectorAdd(const float* a, const float* b, float* result, size_t n, ErrorMessage* error);
 
