@@ -87,7 +87,8 @@ DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id) 
             std::string tok;
             while (is >> tok && tok != ":") key.push_back(std::stoll(tok));
             int t = -1, sp = 0;
-            if ((is >> t >> sp) && t >= 0 && t < kNumIgemmTiles && sp >= 1 && sp <= 64) tune_cache_[key] = {t, sp};
+            if ((is >> t >> sp) && ((t >= 0 && t < kNumIgemmTiles) || (t >= 100 && t < 100 + kNumConvRasterTiles)) && sp >= 1 && sp <= 64)
+                tune_cache_[key] = {t, sp};
         }
     }
     pinned_bytes_ = kChunk * kSlots;
@@ -178,9 +179,50 @@ void DeviceModel::Autotune(PlanInstance& pi) {
             std::vector<int64_t> key = {M, N, s.in.c, s.kh, s.kw, s.sh, s.sw, s.pt, s.pl, s.in.h, s.in.w, s.in.pitch, s.out.pitch,
                                         s.in.nchw, int64_t(s.algo), s.pre_scale_off >= 0, s.bias_off >= 0};
             auto hit = tune_cache_.find(key);
-            if (hit != tune_cache_.end()) { s.tile = hit->second.first; s.splitk = hit->second.second; continue; }
+            auto apply = [&](int enc_tile, int sp) {     // tile >= 100 encodes the raster kernel
+                if (enc_tile >= 100) { s.algo = ConvAlgo::Raster3x3; s.tile = enc_tile - 100; }
+                else s.tile = enc_tile;
+                s.splitk = sp;
+            };
+            if (hit != tune_cache_.end()) { apply(hit->second.first, hit->second.second); continue; }
             float best = 1e30f;
             int best_tile = s.tile, best_split = s.splitk;
+            auto time_trial = [&](const Step& trial) {
+                LaunchStep(pi, trial);                       // warm
+                check(hipEventRecord(e0, stream_), "hipEventRecord");
+                for (int r = 0; r < 3; ++r) LaunchStep(pi, trial);
+                check(hipEventRecord(e1, stream_), "hipEventRecord");
+                check(hipEventSynchronize(e1), "hipEventSynchronize");
+                float ms = 0;
+                check(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime");
+                return ms;
+            };
+            // LDS-window kernel for 3x3/s1/p1 convs without an activation prologue
+            if (s.algo == ConvAlgo::IgemmVec && s.kh == 3 && s.kw == 3 && s.sh == 1 && s.sw == 1 && s.pt == 1 && s.pl == 1 && s.pb == 1 &&
+                s.pr == 1 && s.pre_scale_off < 0) {
+                ConvArgs probe;
+                probe.in = make_arg(pi, s.in);
+                probe.out = make_arg(pi, s.out);
+                probe.w = d_weights_ + s.w_off;
+                probe.kh = 3; probe.kw = 3; probe.pt = 1; probe.pl = 1;
+                const int64_t chunks = (s.in.c + kIgemmBK - 1) / kIgemmBK;
+                const int64_t Mr = s.in.n * (s.in.h + 1) * (s.in.w + 1);
+                for (int t = 0; t < kNumConvRasterTiles; ++t) {
+                    if (!ConvRasterEligible(probe, t)) continue;
+                    const int bn = ConvRasterTileBn(t);
+                    if ((bn > 32 && N <= 32)) continue;
+                    for (int sp : {1, 2, 4, 8}) {
+                        if (sp > chunks || (sp > 1 && int64_t(sp) * M * N > pi.plan.workspace_floats)) continue;
+                        if (sp > 1 && Mr / 64 * sp > 16384) continue;
+                        Step trial = s;
+                        trial.algo = ConvAlgo::Raster3x3;
+                        trial.tile = t;
+                        trial.splitk = sp;
+                        float ms = time_trial(trial);
+                        if (ms < best) { best = ms; best_tile = 100 + t; best_split = sp; }
+                    }
+                }
+            }
             for (int t = 0; t < kNumIgemmTiles; ++t) {
                 const IgemmTile& T = kIgemmTiles[t];
                 if ((T.bn > 32 && N <= 32) || (T.bn > 64 && N <= 64)) continue;
@@ -190,18 +232,11 @@ void DeviceModel::Autotune(PlanInstance& pi) {
                     Step trial = s;
                     trial.tile = t;
                     trial.splitk = sp;
-                    LaunchStep(pi, trial);                       // warm
-                    check(hipEventRecord(e0, stream_), "hipEventRecord");
-                    for (int r = 0; r < 3; ++r) LaunchStep(pi, trial);
-                    check(hipEventRecord(e1, stream_), "hipEventRecord");
-                    check(hipEventSynchronize(e1), "hipEventSynchronize");
-                    float ms = 0;
-                    check(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime");
+                    float ms = time_trial(trial);
                     if (ms < best) { best = ms; best_tile = t; best_split = sp; }
                 }
             }
-            s.tile = best_tile;
-            s.splitk = best_split;
+            apply(best_tile, best_split);
             tune_cache_[key] = {best_tile, best_split};
         }
     } catch (...) {
@@ -236,6 +271,7 @@ void DeviceModel::LaunchStep(const PlanInstance& pi, const Step& s) {
             a.pre_relu = s.pre_relu; a.relu = s.relu;
             a.workspace = pi.workspace;
             if (s.algo == ConvAlgo::Naive) check(LaunchConvNaive(a, stream_), "conv_naive");
+            else if (s.algo == ConvAlgo::Raster3x3) check(LaunchConvRaster3x3(a, s.tile, s.splitk, stream_), "conv3x3_raster");
             else check(LaunchConvIgemm(a, s.tile, s.algo == ConvAlgo::IgemmVec ? 1 : 0, s.splitk, stream_), "conv_igemm");
             break;
         }
@@ -273,6 +309,8 @@ static std::string kernel_label(const Step& s) {
     switch (s.kind) {
         case StepKind::Conv:
             if (s.algo == ConvAlgo::Naive) return "conv_naive_kernel";
+            if (s.algo == ConvAlgo::Raster3x3)
+                return "conv3x3_raster_kernel<t" + std::to_string(s.tile) + (s.splitk > 1 ? ",splitk" + std::to_string(s.splitk) : std::string()) + ">";
             return std::string("conv_igemm_kernel<") + std::to_string(kIgemmTiles[s.tile].bm) + "x" +
                    std::to_string(kIgemmTiles[s.tile].bn) + (s.algo == ConvAlgo::IgemmVec ? ",vec" : ",scalar") +
                    (s.splitk > 1 ? ",splitk" + std::to_string(s.splitk) : std::string()) + ">";

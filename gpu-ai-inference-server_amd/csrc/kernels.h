@@ -45,6 +45,11 @@ struct EltArgs {
 // splitk > 1: the K-tiles are divided over grid.y workgroups that write partial slabs to a.workspace, then a
 // second kernel sums the slabs and applies bias/ReLU (deterministic: no atomics).
 hipError_t LaunchConvIgemm(const ConvArgs& a, int tile, int vec, int splitk, hipStream_t stream);
+// 3x3 / stride 1 / pad 1 with an LDS-resident input window (see kernels.hip).  tile: 0..kNumConvRasterTiles-1.
+constexpr int kNumConvRasterTiles = 6;
+bool ConvRasterEligible(const ConvArgs& a, int tile);
+int ConvRasterTileBn(int tile);
+hipError_t LaunchConvRaster3x3(const ConvArgs& a, int tile, int splitk, hipStream_t stream);
 hipError_t LaunchConvNaive(const ConvArgs& a, hipStream_t stream);
 hipError_t LaunchPool(const PoolArgs& a, hipStream_t stream);
 // out[n, c] = mean over (y, x) of f(in[n, y, x, c]),  f = optional scale/shift/ReLU prologue

@@ -425,6 +425,8 @@ hipError_t LaunchConvIgemm(const ConvArgs& a_in, int tile, int vec, int splitk, 
 #undef IE_CASE
 }
 
+hipError_t InitRasterKernels();
+
 hipError_t InitKernels() {
     hipError_t e;
 #define IE_INIT(T)                                                     \
@@ -433,7 +435,253 @@ hipError_t InitKernels() {
     if ((e = init_igemm_t<T, false, false>()) != hipSuccess) return e;
     IE_INIT(0) IE_INIT(1) IE_INIT(2) IE_INIT(3) IE_INIT(4) IE_INIT(5) IE_INIT(6)
 #undef IE_INIT
-    return hipSuccess;
+    return InitRasterKernels();
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolution with an LDS-resident input window ("raster" kernel)
+//
+// The batch is viewed as ONE 1-D raster of a zero-padded image stack: every image row gets one shared pad column
+// (row pitch PW = W + 1) and every image one shared pad row (RH = H + 1 rows), so raster index p = (b*RH + y)*PW + x.
+// For output position p, tap (ky, kx) reads input raster index p + (ky-1)*PW + (kx-1): the nine taps are nine
+// constant shifts of the same raster.  A workgroup owns BMp consecutive output positions and, per 32-channel slice of
+// Cin, stages the BMp + 2*PW + 2 raster rows it needs into LDS ONCE (instead of nine im2col copies) together with
+// the slice's 9 x BN x 32 weights; the nine taps then run as MFMA GEMMs whose A operand is read straight from the
+// LDS window at row offset (lane + shift).  Because the 32 lanes of an MFMA row block read 32 CONSECUTIVE raster
+// rows, every ds_read_b128 is conflict-free for every shift with the same [rows][32+4] layout as the igemm kernel.
+// Pad positions compute garbage that is never stored (1/(W+1) of the rows).
+// ------------------------------------------------------------------------------------------------
+struct RasterTile { int waves, tmw, tn; };
+constexpr int kNumRasterTiles = 6;
+constexpr RasterTile kRasterTiles[kNumRasterTiles] = {{4, 1, 1}, {4, 2, 1}, {2, 1, 1}, {1, 1, 1}, {4, 1, 2}, {4, 2, 2}};
+
+template <int WAVES, int TMW, int TN>
+__global__ __launch_bounds__(64 * WAVES) void conv3x3_raster_kernel(const ConvArgs a, const int PW, const int RH, const int PR,
+                                                                    const int tiles_n, const int num_tiles) {
+    constexpr int NT = 64 * WAVES;
+    constexpr int BMp = 32 * TMW * WAVES, BN = 32 * TN;
+    constexpr int CK = kIgemmBK, LDP = CK + kIgemmLdsPad;
+    constexpr unsigned OOB = 0x80000000u;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const sP = smem;                                  // [PR][LDP]   input raster window
+    float* const sW = smem + PR * LDP;                       // [9][BN][LDP] weights of the current channel slice
+    int* const sPix = reinterpret_cast<int*>(sW + 9 * BN * LDP);   // [PR] pixel index (b*H + y)*W + x, or -1 for pad rows
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+
+    int tile_m, tile_n;
+    {
+        const int bid = blockIdx.x;
+        const int q = num_tiles >> 3, rem = num_tiles & 7, xcd = bid & 7;
+        const int swz = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+        tile_n = swz % tiles_n;
+        tile_m = swz / tiles_n;
+    }
+    const int P0 = tile_m * BMp, n0 = tile_n * BN;
+    const int Cin = a.in.c, H = a.in.h, W = a.in.w, Cout = a.out.c;
+    const int img = RH * PW;
+    const int Mr = a.in.n * img;
+    const int jbase = P0 - PW - 1;
+    const int isw = int(a.in.sw);
+    const int nsplit = gridDim.y, split = blockIdx.y;
+    const int chunks = (Cin + CK - 1) / CK;
+    const int ch_begin = int(int64_t(chunks) * split / nsplit), ch_end = int(int64_t(chunks) * (split + 1) / nsplit);
+
+    for (int l = tid; l < PR; l += NT) {
+        const int j = jbase + l;
+        int pix = -1;
+        if (j >= 0 && j < Mr) {
+            const int b = j / img;
+            const int rem = j - b * img;
+            const int y = rem / PW, x = rem - y * PW;
+            if (y < H && x < W) pix = (b * H + y) * W + x;
+        }
+        sPix[l] = pix;
+    }
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in.p), 0, int(a.in_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, Cout * 9 * Cin * 4, 0x00020000);
+
+    f32x16 acc[TMW][TN];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    constexpr int U = 4;     // loads kept in flight per thread while staging
+    for (int ch = ch_begin; ch < ch_end; ++ch) {
+        const int c0 = ch * CK;
+        if (ch != ch_begin) __syncthreads();          // every wave is done reading the previous slice
+        // ---- stage the raster window: PR rows x 8 float4 ----
+        const int c4 = (tid & 7) * 4;
+        const bool cok = c0 + c4 < Cin;
+        for (int l0 = tid >> 3; l0 < PR; l0 += U * (NT / 8)) {
+            f32x4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int l = l0 + u * (NT / 8);
+                const int pix = l < PR ? sPix[l] : -1;
+                const unsigned off = (pix >= 0 && cok) ? unsigned(pix * isw + c0 + c4) * 4u : OOB;
+                v[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int l = l0 + u * (NT / 8);
+                if (l < PR) *reinterpret_cast<f32x4*>(sP + l * LDP + c4) = v[u];
+            }
+        }
+        // ---- stage the slice's weights: 9 taps x BN rows x 8 float4 ----
+        constexpr int WITEMS = 9 * BN * 8;
+        for (int q0 = tid; q0 < WITEMS; q0 += U * NT) {
+            f32x4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int q = q0 + u * NT;
+                const int tap = q / (BN * 8);
+                const int rem = q - tap * (BN * 8);
+                const int n = n0 + (rem >> 3);
+                const int c = c0 + (rem & 7) * 4;
+                const unsigned off = (q < WITEMS && n < Cout && c < Cin) ? unsigned((n * 9 + tap) * Cin + c) * 4u : OOB;
+                v[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int q = q0 + u * NT;
+                if (q < WITEMS) *reinterpret_cast<f32x4*>(sW + (q >> 3) * LDP + (q & 7) * 4) = v[u];
+            }
+        }
+        __syncthreads();
+        // ---- nine shifted GEMMs out of LDS ----
+        const float* Abase = sP + (wave * 32 * TMW + r) * LDP + hh * 4;
+        const float* Bbase = sW + r * LDP + hh * 4;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int shift = (tap / 3) * PW + (tap % 3);
+            const float* A = Abase + shift * LDP;
+            const float* B = Bbase + tap * BN * LDP;
+#pragma unroll
+            for (int kk = 0; kk < CK / 8; ++kk) {
+                f32x4 af[TMW], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TMW; ++i) af[i] = *reinterpret_cast<const f32x4*>(A + i * 32 * LDP + kk * 8);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(B + j * 32 * LDP + kk * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: only real pixels are stored (pad positions of the raster are dropped) ----
+    const bool partial = nsplit > 1;
+    const int Mpix = a.in.n * H * W;
+    float* __restrict__ out = partial ? a.workspace + int64_t(split) * Mpix * Cout : a.out.p;
+    const int opitch = partial ? Cout : int(a.out.sw);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + j * 32 + r;
+        const bool nok = n < Cout;
+        const float bv = (!partial && a.bias != nullptr && nok) ? a.bias[n] : 0.f;
+        const bool do_relu = a.relu && !partial;
+#pragma unroll
+        for (int i = 0; i < TMW; ++i) {
+            const int lb = wave * 32 * TMW + i * 32 + 4 * hh + PW + 1;     // window row of this lane's first output position
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int pix = sPix[lb + (e & 3) + 8 * (e >> 2)];
+                float v = acc[i][j][e] + bv;
+                if (do_relu) v = fmaxf(v, 0.f);
+                if (nok && pix >= 0) out[int64_t(pix) * opitch + n] = v;
+            }
+        }
+    }
+}
+
+static size_t raster_lds_bytes(int tile, int PW) {
+    const RasterTile t = kRasterTiles[tile];
+    const int BMp = 32 * t.tmw * t.waves, BN = 32 * t.tn, LDP = kIgemmBK + kIgemmLdsPad;
+    const int PR = BMp + 2 * PW + 2;
+    return size_t(PR) * LDP * 4 + size_t(9) * BN * LDP * 4 + size_t(PR) * 4;
+}
+constexpr size_t kRasterMaxLds = 150 * 1024;
+
+template <int T>
+static hipError_t launch_raster_t(const ConvArgs& a, int splitk, hipStream_t stream) {
+    constexpr RasterTile t = kRasterTiles[T];
+    constexpr int BMp = 32 * t.tmw * t.waves, BN = 32 * t.tn;
+    const int PW = a.in.w + 1, RH = a.in.h + 1;
+    const int PR = BMp + 2 * PW + 2;
+    const int64_t Mr = int64_t(a.in.n) * RH * PW;
+    const int tiles_m = int((Mr + BMp - 1) / BMp), tiles_n = (a.out.c + BN - 1) / BN;
+    const int num_tiles = tiles_m * tiles_n;
+    conv3x3_raster_kernel<t.waves, t.tmw, t.tn>
+        <<<dim3(num_tiles, splitk), dim3(64 * t.waves), raster_lds_bytes(T, PW), stream>>>(a, PW, RH, PR, tiles_n, num_tiles);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || splitk == 1) return e;
+    const int64_t M = int64_t(a.out.n) * a.out.h * a.out.w, total = M * a.out.c;
+    splitk_reduce_kernel<<<dim3(unsigned((total + 255) / 256)), dim3(256), 0, stream>>>(a.workspace, splitk, M, a.out.c, a.bias,
+                                                                                      a.relu, a.out.p, a.out.sw);
+    return hipGetLastError();
+}
+
+int ConvRasterTileBn(int tile) { return (tile >= 0 && tile < kNumRasterTiles) ? 32 * kRasterTiles[tile].tn : 0; }
+
+bool ConvRasterEligible(const ConvArgs& a, int tile) {
+    if (tile < 0 || tile >= kNumRasterTiles) return false;
+    if (a.kh != 3 || a.kw != 3 || a.sh != 1 || a.sw != 1 || a.pt != 1 || a.pl != 1) return false;
+    if (a.out.h != a.in.h || a.out.w != a.in.w || a.pre_scale != nullptr) return false;
+    if (a.in.sc != 1 || a.out.sc != 1 || (a.in.c & 3) || (a.in.sw & 3) || (reinterpret_cast<uintptr_t>(a.in.p) & 15) ||
+        (reinterpret_cast<uintptr_t>(a.w) & 15))
+        return false;
+    if (a.in.sh != a.in.sw * a.in.w || a.in.sn != a.in.sh * a.in.h) return false;      // pixel-major NHWC view
+    if (int64_t(a.in.n) * (a.in.h + 1) * (a.in.w + 1) + 4096 >= (int64_t(1) << 31)) return false;
+    return raster_lds_bytes(tile, a.in.w + 1) <= kRasterMaxLds;
+}
+
+hipError_t LaunchConvRaster3x3(const ConvArgs& a_in, int tile, int splitk, hipStream_t stream) {
+    ConvArgs a = a_in;
+    a.in_bytes = 4 * (int64_t(a.in.n - 1) * a.in.sn + int64_t(a.in.h - 1) * a.in.sh + int64_t(a.in.w - 1) * a.in.sw + int64_t(a.in.c - 1) * a.in.sc + 1);
+    if (!ConvRasterEligible(a, tile) || a.in_bytes >= (int64_t(1) << 31) || int64_t(a.out.c) * 9 * a.in.c * 4 >= (int64_t(1) << 31))
+        return hipErrorInvalidValue;
+    if (splitk < 1 || splitk > 64 || (splitk > 1 && a.workspace == nullptr)) return hipErrorInvalidValue;
+    switch (tile) {
+        case 0: return launch_raster_t<0>(a, splitk, stream);
+        case 1: return launch_raster_t<1>(a, splitk, stream);
+        case 2: return launch_raster_t<2>(a, splitk, stream);
+        case 3: return launch_raster_t<3>(a, splitk, stream);
+        case 4: return launch_raster_t<4>(a, splitk, stream);
+        case 5: return launch_raster_t<5>(a, splitk, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <int T>
+static hipError_t init_raster_t() {
+    constexpr RasterTile t = kRasterTiles[T];
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_raster_kernel<t.waves, t.tmw, t.tn>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, int(kRasterMaxLds));
+}
+
+hipError_t InitRasterKernels() {
+    hipError_t e;
+    if ((e = init_raster_t<0>()) != hipSuccess) return e;
+    if ((e = init_raster_t<1>()) != hipSuccess) return e;
+    if ((e = init_raster_t<2>()) != hipSuccess) return e;
+    if ((e = init_raster_t<3>()) != hipSuccess) return e;
+    if ((e = init_raster_t<4>()) != hipSuccess) return e;
+    return init_raster_t<5>();
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -715,8 +715,23 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                     if (f == "naive") s.algo = ConvAlgo::Naive;
                     else if (f == "scalar" && K <= 2048) s.algo = ConvAlgo::IgemmScalar;
                     else if (f == "igemm" && s.algo == ConvAlgo::Naive) s.algo = vec_ok ? ConvAlgo::IgemmVec : (K <= 2048 ? ConvAlgo::IgemmScalar : ConvAlgo::Naive);
+                    else if (f == "raster") {
+                        const bool eligible = vec_ok && n.kh == 3 && n.kw == 3 && n.sh == 1 && n.sw == 1 && n.pt == 1 && n.pl == 1 &&
+                                              n.pb == 1 && n.pr == 1 && !n.has_pre;
+                        if (eligible) {
+                            s.algo = ConvAlgo::Raster3x3;
+                            s.tile = 0;
+                            if (const char* ft = std::getenv("IE_FORCE_TILE")) { int t = std::atoi(ft); if (t >= 0 && t < 6) s.tile = t; }
+                        } else if (s.algo == ConvAlgo::Naive) s.algo = vec_ok ? ConvAlgo::IgemmVec : (K <= 2048 ? ConvAlgo::IgemmScalar : ConvAlgo::Naive);
+                    }
                 }
-                if (s.algo != ConvAlgo::Naive) {
+                if (s.algo == ConvAlgo::Raster3x3) {
+                    if (const char* fs = std::getenv("IE_FORCE_SPLITK")) {
+                        int v = std::atoi(fs);
+                        if (v >= 1 && v <= 64) s.splitk = v;
+                    }
+                    if (s.splitk > 1) plan.workspace_floats = std::max<int64_t>(plan.workspace_floats, int64_t(s.splitk) * M * N);
+                } else if (s.algo != ConvAlgo::Naive) {
                     // split-K when the output grid cannot fill the chip: aim for >= ~768 workgroups, keep >= 2 K-tiles
                     // per split.  (Deterministic two-pass reduction, see kernels.hip.)
                     const IgemmTile& T = kIgemmTiles[s.tile];
@@ -822,7 +837,7 @@ static std::string json_escape(const std::string& s) {
 
 std::string PlanToJson(const Plan& p) {
     static const char* kinds[] = {"conv", "pool", "gap", "eltwise", "copy"};
-    static const char* algos[] = {"igemm_vec", "igemm_scalar", "naive"};
+    static const char* algos[] = {"igemm_vec", "igemm_scalar", "naive", "raster3x3"};
     std::ostringstream o;
     o.precision(17);
     o << "{\"inputs\":[";

@@ -180,6 +180,32 @@ def test_split_k_reduction(model_repo, splitk):
             os.environ.pop(k, None)
 
 
+@pytest.mark.parametrize("tile", range(6))
+@pytest.mark.parametrize("splitk", [1, 2])
+def test_raster_3x3_kernel(model_repo, tile, splitk):
+    """LDS-window 3x3 kernel (nine shifted GEMMs over the padded raster): every tile shape, with and without split-K,
+    on graphs whose 3x3 convs have ragged channel counts (12, 32, 48) and image sizes 4..32."""
+    os.environ.update(IE_FORCE_ALGO="raster", IE_FORCE_TILE=str(tile), IE_FORCE_SPLITK=str(splitk))
+    try:
+        for name in ("mini_densenet_scale", "mini_resnet_block", "mini_densenet"):
+            mk, iname, ishape = MINI[name]
+            om = O.load_model(mk(models))
+            oname, oshape, _ = om.outputs[0]
+            x = models.synthetic_input(ishape, stream=name)
+            ref64 = np.load(os.path.join(GOLD, name + ".npz"))["output_f64"]
+            d = B.DescribeModel(os.path.join(model_repo, name, "1"), ishape[0])
+            assert any(s.get("algo") == "raster3x3" for s in d["plan"]["steps"]), name
+            m = B.CreateModel(os.path.join(model_repo, name, "1"), name)
+            try:
+                y, _ = infer(m, "", iname, x, oname, oshape)
+                assert rel_err(y, ref64) < RTOL, (name, tile, splitk, rel_err(y, ref64))
+            finally:
+                m.Destroy()
+    finally:
+        for k in ("IE_FORCE_SPLITK", "IE_FORCE_ALGO", "IE_FORCE_TILE"):
+            os.environ.pop(k, None)
+
+
 def test_naive_kernel_agrees(model_repo):
     os.environ["IE_FORCE_ALGO"] = "naive"
     try:
