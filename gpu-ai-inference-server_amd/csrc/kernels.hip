@@ -78,16 +78,25 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    // Fragment reads are software-pipelined by hand: the ds_read_b128s of step kk+1 are issued BEFORE the MFMAs of step kk
+    // (two register sets), otherwise every group of MFMAs starts with an exposed LDS round trip.
     auto compute = [&](int buf) {
         const float* A = sA + buf * BM * LDP + (wm_i * TM * 32 + r) * LDP + hh * 4;
         const float* B = sB + buf * BN * LDP + (wn_i * TN * 32 + r) * LDP + hh * 4;
+        f32x4 af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(A + i * 32 * LDP);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(B + j * 32 * LDP);
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
-            f32x4 af[TM], bf[TN];
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < BK / 8) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(A + i * 32 * LDP + kk * 8);
+                for (int i = 0; i < TM; ++i) af[nxt][i] = *reinterpret_cast<const f32x4*>(A + i * 32 * LDP + (kk + 1) * 8);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(B + j * 32 * LDP + kk * 8);
+                for (int j = 0; j < TN; ++j) bf[nxt][j] = *reinterpret_cast<const f32x4*>(B + j * 32 * LDP + (kk + 1) * 8);
+            }
             // lanes 0-31 carry k = kk*8+e, lanes 32-63 carry k = kk*8+4+e, identically for A and B,
             // so the four K=2 MFMAs together cover the 8 k-values of this chunk.
 #pragma unroll
@@ -96,7 +105,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][e], bf[cur][j][e], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);      // next step's DS reads first ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);  // ... then this step's MFMAs
         }
     };
 
@@ -454,8 +465,10 @@ hipError_t InitKernels() {
 struct RasterTile { int waves, tmw, tn; };
 constexpr int kNumRasterTiles = 6;
 constexpr RasterTile kRasterTiles[kNumRasterTiles] = {{4, 1, 1}, {4, 2, 1}, {2, 1, 1}, {1, 1, 1}, {4, 1, 2}, {4, 2, 2}};
+// window float4s per thread that the register-prefetch variant holds (0 = synchronous staging only)
+constexpr int kRasterPit[kNumRasterTiles] = {8, 12, 12, 0, 8, 12};
 
-template <int WAVES, int TMW, int TN>
+template <int WAVES, int TMW, int TN, int PIT>
 __global__ __launch_bounds__(64 * WAVES) void conv3x3_raster_kernel(const ConvArgs a, const int PW, const int RH, const int PR,
                                                                     const int tiles_n, const int num_tiles) {
     constexpr int NT = 64 * WAVES;
@@ -515,6 +528,108 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_raster_kernel(const ConvAr
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    // ---- nine shifted GEMMs out of LDS: 36 (tap, kk) steps, fragment reads one step ahead of the MFMAs ----
+    auto compute_slice = [&]() {
+        const float* Abase = sP + (wave * 32 * TMW + r) * LDP + hh * 4;
+        const float* Bbase = sW + r * LDP + hh * 4;
+        constexpr int KSTEPS = CK / 8, STEPS = 9 * KSTEPS;
+        f32x4 af[2][TMW], bf[2][TN];
+        auto read_step = [&](int st, int slot) {
+            const int tap = st / KSTEPS, kk = st - tap * KSTEPS;
+            const int shift = (tap / 3) * PW + (tap % 3);
+            const float* A = Abase + shift * LDP + kk * 8;
+            const float* B = Bbase + tap * BN * LDP + kk * 8;
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) af[slot][i] = *reinterpret_cast<const f32x4*>(A + i * 32 * LDP);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[slot][j] = *reinterpret_cast<const f32x4*>(B + j * 32 * LDP);
+        };
+        read_step(0, 0);
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+            const int cur = st & 1;
+            if (st + 1 < STEPS) read_step(st + 1, cur ^ 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TMW; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][e], bf[cur][j][e], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, TMW + TN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * TMW * TN, 0);
+        }
+    };
+
+    if constexpr (PIT > 0) {
+        // ---- register-prefetched staging: the next channel slice's window + weights are loaded (all loads in flight at
+        //      once) while the current slice is on the matrix cores, then committed to LDS between two barriers ----
+        constexpr int RPP = NT / 8;                 // window rows covered per pass of the workgroup
+        constexpr int WIT = 9 * BN * 8 / NT;        // weight float4s per thread per slice
+        static_assert(9 * BN * 8 % NT == 0, "weight items must divide evenly");
+        const int c4 = (tid & 7) * 4;
+        int poff[PIT];                               // element offset of (pixel, c4) or -1
+#pragma unroll
+        for (int i = 0; i < PIT; ++i) {
+            const int l = (tid >> 3) + i * RPP;
+            const int pix = l < PR ? sPix[l] : -1;
+            poff[i] = pix >= 0 ? pix * isw + c4 : -1;
+        }
+        int woff[WIT];
+#pragma unroll
+        for (int i = 0; i < WIT; ++i) {
+            const int q = tid + i * NT;
+            const int tap = q / (BN * 8);
+            const int rem = q - tap * (BN * 8);
+            const int n = n0 + (rem >> 3);
+            woff[i] = n < Cout ? (n * 9 + tap) * Cin + (rem & 7) * 4 : -1;
+        }
+        f32x4 pv[PIT], wv[WIT];
+        auto issue = [&](int ch) {
+            const int c0 = ch * CK;
+            const bool cok = c0 + c4 < Cin;
+#pragma unroll
+            for (int i = 0; i < PIT; ++i) {
+                const unsigned off = (poff[i] >= 0 && cok) ? unsigned(poff[i] + c0) * 4u : OOB;
+                pv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0));
+            }
+#pragma unroll
+            for (int i = 0; i < WIT; ++i) {
+                const int cw = c0 + ((tid + i * NT) & 7) * 4;
+                const unsigned off = (woff[i] >= 0 && cw < Cin) ? unsigned(woff[i] + c0) * 4u : OOB;
+                wv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0));
+            }
+        };
+        auto commit = [&]() {
+#pragma unroll
+            for (int i = 0; i < PIT; ++i) {
+                const int l = (tid >> 3) + i * RPP;
+                if (l < PR) *reinterpret_cast<f32x4*>(sP + l * LDP + c4) = pv[i];
+            }
+#pragma unroll
+            for (int i = 0; i < WIT; ++i) {
+                const int q = tid + i * NT;
+                *reinterpret_cast<f32x4*>(sW + (q >> 3) * LDP + (q & 7) * 4) = wv[i];
+            }
+        };
+        if (ch_begin < ch_end) {
+            issue(ch_begin);
+            commit();
+            __syncthreads();
+            for (int ch = ch_begin; ch < ch_end; ++ch) {
+                const bool more = ch + 1 < ch_end;
+                if (more) issue(ch + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                compute_slice();
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) {
+                    __syncthreads();      // every wave is done reading the current slice
+                    commit();
+                    __syncthreads();
+                }
+            }
+        }
+    } else {
     constexpr int U = 4;     // loads kept in flight per thread while staging
     for (int ch = ch_begin; ch < ch_end; ++ch) {
         const int c0 = ch * CK;
@@ -558,30 +673,8 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_raster_kernel(const ConvAr
             }
         }
         __syncthreads();
-        // ---- nine shifted GEMMs out of LDS ----
-        const float* Abase = sP + (wave * 32 * TMW + r) * LDP + hh * 4;
-        const float* Bbase = sW + r * LDP + hh * 4;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int shift = (tap / 3) * PW + (tap % 3);
-            const float* A = Abase + shift * LDP;
-            const float* B = Bbase + tap * BN * LDP;
-#pragma unroll
-            for (int kk = 0; kk < CK / 8; ++kk) {
-                f32x4 af[TMW], bf[TN];
-#pragma unroll
-                for (int i = 0; i < TMW; ++i) af[i] = *reinterpret_cast<const f32x4*>(A + i * 32 * LDP + kk * 8);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(B + j * 32 * LDP + kk * 8);
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int i = 0; i < TMW; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
-            }
-        }
+        compute_slice();
+    }
     }
 
     // ---- epilogue: only real pixels are stored (pad positions of the raster are dropped) ----
@@ -626,8 +719,13 @@ static hipError_t launch_raster_t(const ConvArgs& a, int splitk, hipStream_t str
     const int64_t Mr = int64_t(a.in.n) * RH * PW;
     const int tiles_m = int((Mr + BMp - 1) / BMp), tiles_n = (a.out.c + BN - 1) / BN;
     const int num_tiles = tiles_m * tiles_n;
-    conv3x3_raster_kernel<t.waves, t.tmw, t.tn>
-        <<<dim3(num_tiles, splitk), dim3(64 * t.waves), raster_lds_bytes(T, PW), stream>>>(a, PW, RH, PR, tiles_n, num_tiles);
+    constexpr int PIT = kRasterPit[T];
+    if (PIT > 0 && PR <= PIT * (64 * t.waves / 8))
+        conv3x3_raster_kernel<t.waves, t.tmw, t.tn, PIT>
+            <<<dim3(num_tiles, splitk), dim3(64 * t.waves), raster_lds_bytes(T, PW), stream>>>(a, PW, RH, PR, tiles_n, num_tiles);
+    else
+        conv3x3_raster_kernel<t.waves, t.tmw, t.tn, 0>
+            <<<dim3(num_tiles, splitk), dim3(64 * t.waves), raster_lds_bytes(T, PW), stream>>>(a, PW, RH, PR, tiles_n, num_tiles);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || splitk == 1) return e;
     const int64_t M = int64_t(a.out.n) * a.out.h * a.out.w, total = M * a.out.c;
@@ -670,7 +768,10 @@ hipError_t LaunchConvRaster3x3(const ConvArgs& a_in, int tile, int splitk, hipSt
 template <int T>
 static hipError_t init_raster_t() {
     constexpr RasterTile t = kRasterTiles[T];
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_raster_kernel<t.waves, t.tmw, t.tn>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_raster_kernel<t.waves, t.tmw, t.tn, 0>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(kRasterMaxLds));
+    if (e != hipSuccess || kRasterPit[T] == 0) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_raster_kernel<t.waves, t.tmw, t.tn, kRasterPit[T]>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, int(kRasterMaxLds));
 }
 
