@@ -33,6 +33,7 @@ TensorArg make_arg(const PlanInstance& pi, const View& v) {
 
 constexpr size_t kChunk = size_t(4) << 20;   // pinned staging chunk
 constexpr int64_t kTuneWorkspaceFloats = int64_t(16) << 20;   // 64 MiB of split-K slabs available to the autotuner
+constexpr int kNumCounters = 1 << 16;
 constexpr int kSlots = 4;
 
 std::once_flag g_kernels_once;
@@ -76,6 +77,10 @@ DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id) 
     const char* ng = std::getenv("IE_DISABLE_GRAPH");
     use_graph_ = !(ng && ng[0] == '1');
     const char* at = std::getenv("IE_AUTOTUNE");
+    // Measured on MI355X (DenseNet-121 B=32): the in-launch combine (agent-scope release/acquire per tile) costs more than
+    // the kernel boundary it removes: 3.63 ms/step vs 3.42 ms/step with the separate reduce kernel.  Two-pass is the default.
+    const char* tp = std::getenv("IE_SPLITK_IN_LAUNCH");
+    two_pass_splitk_ = !(tp && tp[0] == '1');
     autotune_ = !(at && at[0] == '0') && !std::getenv("IE_FORCE_TILE") && !std::getenv("IE_FORCE_SPLITK") && !std::getenv("IE_FORCE_ALGO");
     // Optional persistent tuning cache (IE_TUNE_CACHE=<file>): "<17 signature ints> : <tile> <splitk>" per line.
     if (const char* tc = std::getenv("IE_TUNE_CACHE")) {
@@ -102,6 +107,7 @@ DeviceModel::~DeviceModel() {
         if (kv.second->graph_exec) (void)hipGraphExecDestroy(kv.second->graph_exec);
         for (float* b : kv.second->buffers) if (b) (void)hipFree(b);
         if (kv.second->workspace) (void)hipFree(kv.second->workspace);
+        if (kv.second->counters) (void)hipFree(kv.second->counters);
     }
     if (d_weights_) (void)hipFree(d_weights_);
     if (pinned_) (void)hipHostFree(pinned_);
@@ -135,11 +141,15 @@ PlanInstance& DeviceModel::Prepare(const std::vector<std::vector<int64_t>>& shap
         device_bytes_ += bytes;
         pi->buffers.push_back(p);
     }
-    if (autotune_) pi->plan.workspace_floats = std::max<int64_t>(pi->plan.workspace_floats, kTuneWorkspaceFloats);
-    if (pi->plan.workspace_floats > 0) {
-        size_t bytes = size_t(pi->plan.workspace_floats) * sizeof(float);
+    {   // split-K scratch: slabs + per-tile arrival counters (tile-padded slabs need up to 2x the exact S*M*N)
+        pi->workspace_floats = std::max<int64_t>(2 * pi->plan.workspace_floats, kTuneWorkspaceFloats);
+        size_t bytes = size_t(pi->workspace_floats) * sizeof(float);
         check(hipMalloc(reinterpret_cast<void**>(&pi->workspace), bytes), "hipMalloc(workspace)");
         device_bytes_ += bytes;
+        if (!two_pass_splitk_) {
+            check(hipMalloc(reinterpret_cast<void**>(&pi->counters), kNumCounters * sizeof(int)), "hipMalloc(counters)");
+            check(hipMemsetAsync(pi->counters, 0, kNumCounters * sizeof(int), stream_), "hipMemset(counters)");
+        }
     }
     check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
     if (autotune_) Autotune(*pi);
@@ -212,8 +222,9 @@ void DeviceModel::Autotune(PlanInstance& pi) {
                     const int bn = ConvRasterTileBn(t);
                     if ((bn > 32 && N <= 32)) continue;
                     for (int sp : {1, 2, 4, 8}) {
-                        if (sp > chunks || (sp > 1 && int64_t(sp) * M * N > pi.plan.workspace_floats)) continue;
+                        if (sp > chunks) continue;
                         if (sp > 1 && Mr / 64 * sp > 16384) continue;
+                        if (sp > 1 && int64_t(sp) * (M + 256) * (N + 64) * 2 > pi.workspace_floats) continue;
                         Step trial = s;
                         trial.algo = ConvAlgo::Raster3x3;
                         trial.tile = t;
@@ -228,7 +239,9 @@ void DeviceModel::Autotune(PlanInstance& pi) {
                 if ((T.bn > 32 && N <= 32) || (T.bn > 64 && N <= 64)) continue;
                 const int64_t wgs = ((M + T.bm - 1) / T.bm) * ((N + T.bn - 1) / T.bn);
                 for (int sp : kSplits) {
-                    if (sp > 1 && (KT / sp < 2 || int64_t(sp) * M * N > pi.plan.workspace_floats || wgs * sp > 8192 || wgs >= 1024)) continue;
+                    if (sp > 1 && (KT / sp < 2 || int64_t(sp) * wgs * T.bm * T.bn > pi.workspace_floats || wgs > kNumCounters ||
+                                   wgs * sp > 8192 || wgs >= 1024))
+                        continue;
                     Step trial = s;
                     trial.tile = t;
                     trial.splitk = sp;
@@ -270,6 +283,9 @@ void DeviceModel::LaunchStep(const PlanInstance& pi, const Step& s) {
             a.kh = s.kh; a.kw = s.kw; a.sh = s.sh; a.sw = s.sw; a.pt = s.pt; a.pl = s.pl;
             a.pre_relu = s.pre_relu; a.relu = s.relu;
             a.workspace = pi.workspace;
+            a.workspace_floats = pi.workspace_floats;
+            a.counters = pi.counters;
+            a.num_counters = pi.counters ? kNumCounters : 0;
             if (s.algo == ConvAlgo::Naive) check(LaunchConvNaive(a, stream_), "conv_naive");
             else if (s.algo == ConvAlgo::Raster3x3) check(LaunchConvRaster3x3(a, s.tile, s.splitk, stream_), "conv3x3_raster");
             else check(LaunchConvIgemm(a, s.tile, s.algo == ConvAlgo::IgemmVec ? 1 : 0, s.splitk, stream_), "conv_igemm");

@@ -24,7 +24,9 @@ struct StepTiming {
 struct PlanInstance {
     Plan plan;
     std::vector<float*> buffers;       // device activation buffers (plan.buffer_floats)
-    float* workspace = nullptr;        // split-K slabs (plan.workspace_floats)
+    float* workspace = nullptr;        // split-K slabs
+    int64_t workspace_floats = 0;
+    int* counters = nullptr;           // split-K arrival counters (zero between launches)
     hipGraphExec_t graph_exec = nullptr;
     bool graph_ready = false;
 };
@@ -74,6 +76,7 @@ private:
     size_t device_bytes_ = 0;
     bool use_graph_ = true;
     bool autotune_ = true;
+    bool two_pass_splitk_ = true;      // IE_SPLITK_IN_LAUNCH=1 selects the in-launch combine instead of the reduce kernel
     std::map<std::vector<int64_t>, std::pair<int, int>> tune_cache_;   // conv signature -> (tile, splitk)
     std::map<std::vector<int64_t>, std::unique_ptr<PlanInstance>> plans_;
     PlanInstance* current_ = nullptr;

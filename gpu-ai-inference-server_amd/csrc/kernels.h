@@ -23,7 +23,10 @@ struct ConvArgs {
     const float* pre_shift = nullptr;
     int kh = 1, kw = 1, sh = 1, sw = 1, pt = 0, pl = 0;
     int pre_relu = 0, relu = 0;
-    float* workspace = nullptr;        // split-K partial slabs [splitk][M][Cout] (only when splitk > 1)
+    float* workspace = nullptr;        // split-K partial slabs (only when splitk > 1)
+    int64_t workspace_floats = 0;      // capacity of `workspace`
+    int* counters = nullptr;           // per-tile arrival counters for the in-launch combine; null = two-pass reduce kernel
+    int num_counters = 0;
     int debug = 0;                     // timing-only ablation bits (IE_DEBUG_ABLATE), 0 in production
     int64_t in_bytes = 0;              // filled by LaunchConvIgemm: byte span of the input view (buffer descriptor range)
 };
@@ -42,8 +45,10 @@ struct EltArgs {
 };
 
 // vec: 1 = float4 NHWC operand staging, 0 = scalar gather staging.  tile: index into kIgemmTiles.
-// splitk > 1: the K-tiles are divided over grid.y workgroups that write partial slabs to a.workspace, then a
-// second kernel sums the slabs and applies bias/ReLU (deterministic: no atomics).
+// splitk > 1: the K-tiles are divided over grid.y workgroups that write partial slabs to a.workspace; the slabs are
+// combined inside the same launch by the last-arriving workgroup of each tile (a.counters != null) or by a second
+// kernel (a.counters == null).  Both sum in slice order: deterministic, no float atomics.
+bool SplitKWorkspaceOk(int64_t workspace_floats, int num_counters, int splitk, int64_t num_tiles, int tile_elems);
 hipError_t LaunchConvIgemm(const ConvArgs& a, int tile, int vec, int splitk, hipStream_t stream);
 // 3x3 / stride 1 / pad 1 with an LDS-resident input window (see kernels.hip).  tile: 0..kNumConvRasterTiles-1.
 constexpr int kNumConvRasterTiles = 6;

@@ -31,6 +31,58 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
+// In-launch split-K combine ("the last arriver reduces").  Every K-slice workgroup of an output tile stores its raw
+// accumulators to a slab, publishes them with ONE agent-scope release, and draws a ticket from the tile's counter; the
+// workgroup that draws the last ticket acquires (agent scope), sums ALL slabs in slice order (its own included, from
+// memory, so the result does not depend on arrival order: bitwise reproducible) and runs the normal bias/ReLU epilogue.
+// Placement independent (no assumption on dispatch order / XCD), nobody spins, so it cannot deadlock.
+// Counters are zero at allocation and reset by the last arriver.
+// ------------------------------------------------------------------------------------------------
+template <int TM, int TN, int NT>
+__device__ __forceinline__ bool splitk_combine(f32x16 (&acc)[TM][TN], float* __restrict__ ws, int* counters, const int tile,
+                                               const int num_tiles, const int split, const int nsplit, const int tid, int* lds_word) {
+    constexpr int PER_WG = TM * TN * 16 * NT;
+    float* slab = ws + (int64_t(split) * num_tiles + tile) * PER_WG;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) slab[((i * TN + j) * 16 + e) * NT + tid] = acc[i][j][e];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its stores ...
+    __syncthreads();                                            // ... before one lane publishes for the workgroup
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the write-back must finish before the ticket is visible
+        *lds_word = __hip_atomic_fetch_add(counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (*lds_word != nsplit - 1) return false;
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // drop this CU's stale L1 lines of the other slabs
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) {
+        const float* p = ws + (int64_t(sp) * num_tiles + tile) * PER_WG;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] += p[((i * TN + j) * 16 + e) * NT + tid];
+    }
+    if (tid == 0) __hip_atomic_store(counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
 // implicit-GEMM convolution on v_mfma_f32_32x32x2_f32
 // ------------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, bool VEC, bool PRE>
@@ -309,9 +361,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------------
-    // nsplit == 1: bias + ReLU, store Cout channels at the view's channel offset.
-    // nsplit  > 1: raw partial sums to workspace slab [split][M][Cout]; splitk_reduce_kernel finishes the job.
-    const bool partial = nsplit > 1;
+    // nsplit > 1: in-launch combine; only the last-arriving K-slice of a tile continues into the store epilogue
+    // (or, with the two-pass fallback, every slice stores its raw slab [split][M][Cout] for splitk_reduce_kernel).
+    const int tile_id = tile_m * tiles_n + tile_n;
+    if (nsplit > 1 && a.counters != nullptr) {
+        if (!splitk_combine<TM, TN, NT>(acc, a.workspace, a.counters, tile_id, num_tiles, split, nsplit, tid, reinterpret_cast<int*>(smem)))
+            return;
+    }
+    const bool partial = nsplit > 1 && a.counters == nullptr;
     float* __restrict__ out = partial ? a.workspace + int64_t(split) * M * Cout : a.out.p;
     const int opitch = partial ? Cout : int(a.out.sw);
     // finish the values in place first, so the stores below issue back-to-back from distinct registers
@@ -372,6 +429,17 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, const int nsp
     out[m * opitch + n] = v;
 }
 
+// Does the split-K scratch of this launch fit the workspace / counter arrays handed in by the executor?
+static bool SplitKFits(const ConvArgs& a, int splitk, int num_tiles, int tile_elems, int64_t out_elems) {
+    if (a.workspace == nullptr) return false;
+    if (a.counters != nullptr) return num_tiles <= a.num_counters && int64_t(splitk) * num_tiles * tile_elems <= a.workspace_floats;
+    return int64_t(splitk) * out_elems <= a.workspace_floats;
+}
+
+bool SplitKWorkspaceOk(int64_t workspace_floats, int num_counters, int splitk, int64_t num_tiles, int tile_elems) {
+    return num_tiles <= num_counters && int64_t(splitk) * num_tiles * tile_elems <= workspace_floats;
+}
+
 template <int T, bool VEC>
 static size_t igemm_lds_bytes() {
     constexpr IgemmTile t = kIgemmTiles[T];
@@ -386,10 +454,11 @@ static hipError_t launch_igemm_t(const ConvArgs& a, int splitk, hipStream_t stre
     const int64_t M = int64_t(a.out.n) * a.out.h * a.out.w;
     const int tiles_m = int((M + t.bm - 1) / t.bm), tiles_n = (a.out.c + t.bn - 1) / t.bn;
     const int num_tiles = tiles_m * tiles_n;
+    if (splitk > 1 && !SplitKFits(a, splitk, num_tiles, t.bm * t.bn, M * a.out.c)) return hipErrorInvalidValue;
     conv_igemm_kernel<t.bm, t.bn, t.wm, t.wn, VEC, PRE>
         <<<dim3(num_tiles, splitk), dim3(64 * t.wm * t.wn), igemm_lds_bytes<T, VEC>(), stream>>>(a, tiles_n, num_tiles);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess || splitk == 1) return e;
+    if (e != hipSuccess || splitk == 1 || a.counters != nullptr) return e;
     const int64_t total = M * a.out.c;
     splitk_reduce_kernel<<<dim3(unsigned((total + 255) / 256)), dim3(256), 0, stream>>>(a.workspace, splitk, M, a.out.c, a.bias,
                                                                                       a.relu, a.out.p, a.out.sw);
@@ -678,7 +747,12 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_raster_kernel(const ConvAr
     }
 
     // ---- epilogue: only real pixels are stored (pad positions of the raster are dropped) ----
-    const bool partial = nsplit > 1;
+    const int tile_id = tile_m * tiles_n + tile_n;
+    if (nsplit > 1 && a.counters != nullptr) {
+        if (!splitk_combine<TMW, TN, NT>(acc, a.workspace, a.counters, tile_id, num_tiles, split, nsplit, tid, reinterpret_cast<int*>(sP)))
+            return;
+    }
+    const bool partial = nsplit > 1 && a.counters == nullptr;
     const int Mpix = a.in.n * H * W;
     float* __restrict__ out = partial ? a.workspace + int64_t(split) * Mpix * Cout : a.out.p;
     const int opitch = partial ? Cout : int(a.out.sw);
@@ -719,6 +793,7 @@ static hipError_t launch_raster_t(const ConvArgs& a, int splitk, hipStream_t str
     const int64_t Mr = int64_t(a.in.n) * RH * PW;
     const int tiles_m = int((Mr + BMp - 1) / BMp), tiles_n = (a.out.c + BN - 1) / BN;
     const int num_tiles = tiles_m * tiles_n;
+    if (splitk > 1 && !SplitKFits(a, splitk, num_tiles, BMp * BN, int64_t(a.out.n) * a.out.h * a.out.w * a.out.c)) return hipErrorInvalidValue;
     constexpr int PIT = kRasterPit[T];
     if (PIT > 0 && PR <= PIT * (64 * t.waves / 8))
         conv3x3_raster_kernel<t.waves, t.tmw, t.tn, PIT>
@@ -727,7 +802,7 @@ static hipError_t launch_raster_t(const ConvArgs& a, int splitk, hipStream_t str
         conv3x3_raster_kernel<t.waves, t.tmw, t.tn, 0>
             <<<dim3(num_tiles, splitk), dim3(64 * t.waves), raster_lds_bytes(T, PW), stream>>>(a, PW, RH, PR, tiles_n, num_tiles);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess || splitk == 1) return e;
+    if (e != hipSuccess || splitk == 1 || a.counters != nullptr) return e;
     const int64_t M = int64_t(a.out.n) * a.out.h * a.out.w, total = M * a.out.c;
     splitk_reduce_kernel<<<dim3(unsigned((total + 255) / 256)), dim3(256), 0, stream>>>(a.workspace, splitk, M, a.out.c, a.bias,
                                                                                       a.relu, a.out.p, a.out.sw);

@@ -154,11 +154,14 @@ def test_every_igemm_tile_and_loader(model_repo, tile, algo):
         del os.environ["IE_FORCE_TILE"], os.environ["IE_FORCE_ALGO"]
 
 
+@pytest.mark.parametrize("in_launch", ["0", "1"])
 @pytest.mark.parametrize("splitk", [2, 3, 7])
-def test_split_k_reduction(model_repo, splitk):
-    """K-tiles split over several workgroups + deterministic slab reduction (bias/ReLU applied after the sum)."""
+def test_split_k_reduction(model_repo, splitk, in_launch):
+    """K-tiles split over several workgroups; slabs combined in-launch by the last-arriving workgroup (agent-scope
+    release/acquire + ticket counter) or by the two-pass reduce kernel.  Both sum in slice order: deterministic."""
     os.environ["IE_FORCE_SPLITK"] = str(splitk)
     os.environ["IE_FORCE_ALGO"] = "igemm"
+    os.environ["IE_SPLITK_IN_LAUNCH"] = in_launch
     try:
         for name, tile in (("mini_densenet_scale", 5), ("mini_resnet_block", 4), ("mini_gemm_mlp", 3)):
             os.environ["IE_FORCE_TILE"] = str(tile)
@@ -176,7 +179,7 @@ def test_split_k_reduction(model_repo, splitk):
             finally:
                 m.Destroy()
     finally:
-        for k in ("IE_FORCE_SPLITK", "IE_FORCE_ALGO", "IE_FORCE_TILE"):
+        for k in ("IE_FORCE_SPLITK", "IE_FORCE_ALGO", "IE_FORCE_TILE", "IE_SPLITK_IN_LAUNCH"):
             os.environ.pop(k, None)
 
 
