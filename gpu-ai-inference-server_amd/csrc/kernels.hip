@@ -85,21 +85,25 @@ __device__ __forceinline__ bool splitk_combine(f32x16 (&acc)[TM][TN], float* __r
 // ------------------------------------------------------------------------------------------------
 // implicit-GEMM convolution on v_mfma_f32_32x32x2_f32
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool VEC, bool PRE>
-__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs a, const int tiles_n, const int num_tiles) {
-    constexpr int NT = 64 * WM * WN;
+template <int BM, int BN, int WM, int WN, int KG, bool VEC, bool PRE>
+__global__ __launch_bounds__(64 * WM * WN * KG) void conv_igemm_kernel(const ConvArgs a, const int tiles_n, const int num_tiles) {
+    constexpr int NT = 64 * WM * WN;            // threads of one K-group (they stage and compute one K-slice together)
     constexpr int BK = kIgemmBK;
     constexpr int LDP = BK + kIgemmLdsPad;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int GROUP_LDS = 2 * (BM + BN) * LDP;   // floats of LDS per K-group (double-buffered A and B tiles)
     static_assert(TM >= 1 && TN >= 1 && BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "bad tile");
+    static_assert(KG == 1 || (VEC && BM * BN <= GROUP_LDS), "K-groups need the vector path and room for the partial tile");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* const sA = smem;                   // [2][BM][LDP]
-    float* const sB = smem + 2 * BM * LDP;    // [2][BN][LDP]
+    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave_all / (WM * WN);       // K-group of this wave
+    float* const sA = smem + grp * GROUP_LDS;   // [2][BM][LDP]
+    float* const sB = sA + 2 * BM * LDP;        // [2][BN][LDP]
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x - grp * NT;     // thread index inside the K-group
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_all - grp * (WM * WN);
     const int wm_i = wave / WN, wn_i = wave % WN;
     const int r = lane & 31, hh = lane >> 5;
 
@@ -260,19 +264,49 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
                 *reinterpret_cast<f32x4*>(sB + buf * BN * LDP + (rw + i * ROWS_PER_PASS) * LDP + c4) = rb[i];
         };
 
-        if (kt_begin < kt_end) {
-            issue_loads(kt_begin);
-            finish_store(0);
+        // This K-group's contiguous share of the workgroup's K-tiles; every group runs the same number of barrier rounds.
+        const int nkt = kt_end - kt_begin;
+        const int gb = kt_begin + int(int64_t(nkt) * grp / KG), ge = kt_begin + int(int64_t(nkt) * (grp + 1) / KG);
+        const int rounds = (nkt + KG - 1) / KG;
+        if (nkt > 0) {
+            if (gb < ge) {
+                issue_loads(gb);
+                finish_store(0);
+            }
             __syncthreads();
-            for (int kt = kt_begin; kt < kt_end; ++kt) {
-                const int buf = (kt - kt_begin) & 1;
-                const bool more = kt + 1 < kt_end;
+            for (int it = 0; it < rounds; ++it) {
+                const int kt = gb + it;
+                const int buf = it & 1;
+                const bool active = kt < ge, more = kt + 1 < ge;
                 if (more && !(a.debug & 1)) issue_loads(kt + 1);
                 __builtin_amdgcn_sched_barrier(0);       // loads stay ahead of the MFMA block ...
-                if (!(a.debug & 2)) compute(buf);
+                if (active && !(a.debug & 2)) compute(buf);
                 __builtin_amdgcn_sched_barrier(0);       // ... and their consumers stay behind it
                 if (more && !(a.debug & 4)) finish_store(buf ^ 1);
                 if (!(a.debug & 8)) __syncthreads();
+            }
+        }
+        if constexpr (KG > 1) {
+            // Sum the K-groups' partial tiles through LDS (each group's own staging area is free now), in group order.
+            if (grp > 0) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) sA[((i * TN + j) * 16 + e) * NT + tid] = acc[i][j][e];
+            }
+            __syncthreads();
+            if (grp > 0) return;
+#pragma unroll
+            for (int g = 1; g < KG; ++g) {
+                const float* p = smem + g * GROUP_LDS;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[i][j][e] += p[((i * TN + j) * 16 + e) * NT + tid];
             }
         }
     } else {
@@ -443,7 +477,7 @@ bool SplitKWorkspaceOk(int64_t workspace_floats, int num_counters, int splitk, i
 template <int T, bool VEC>
 static size_t igemm_lds_bytes() {
     constexpr IgemmTile t = kIgemmTiles[T];
-    size_t b = size_t(2) * (t.bm + t.bn) * (kIgemmBK + kIgemmLdsPad) * sizeof(float);
+    size_t b = size_t(2) * (t.bm + t.bn) * (kIgemmBK + kIgemmLdsPad) * sizeof(float) * t.kg;
     if (!VEC) b += size_t(t.bm) * (sizeof(int64_t) + 2 * sizeof(int));
     return b;
 }
@@ -455,8 +489,9 @@ static hipError_t launch_igemm_t(const ConvArgs& a, int splitk, hipStream_t stre
     const int tiles_m = int((M + t.bm - 1) / t.bm), tiles_n = (a.out.c + t.bn - 1) / t.bn;
     const int num_tiles = tiles_m * tiles_n;
     if (splitk > 1 && !SplitKFits(a, splitk, num_tiles, t.bm * t.bn, M * a.out.c)) return hipErrorInvalidValue;
-    conv_igemm_kernel<t.bm, t.bn, t.wm, t.wn, VEC, PRE>
-        <<<dim3(num_tiles, splitk), dim3(64 * t.wm * t.wn), igemm_lds_bytes<T, VEC>(), stream>>>(a, tiles_n, num_tiles);
+    if (t.kg > 1 && splitk > 1 && a.counters != nullptr) return hipErrorInvalidValue;   // in-launch combine assumes one K-group
+    conv_igemm_kernel<t.bm, t.bn, t.wm, t.wn, t.kg, VEC, PRE>
+        <<<dim3(num_tiles, splitk), dim3(64 * t.wm * t.wn * t.kg), igemm_lds_bytes<T, VEC>(), stream>>>(a, tiles_n, num_tiles);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || splitk == 1 || a.counters != nullptr) return e;
     const int64_t total = M * a.out.c;
@@ -468,7 +503,7 @@ static hipError_t launch_igemm_t(const ConvArgs& a, int splitk, hipStream_t stre
 template <int T, bool VEC, bool PRE>
 static hipError_t init_igemm_t() {
     constexpr IgemmTile t = kIgemmTiles[T];
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<t.bm, t.bn, t.wm, t.wn, VEC, PRE>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<t.bm, t.bn, t.wm, t.wn, t.kg, VEC, PRE>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, int(igemm_lds_bytes<T, VEC>()));
 }
 
@@ -498,11 +533,17 @@ hipError_t LaunchConvIgemm(const ConvArgs& a_in, int tile, int vec, int splitk, 
     case T:                                                                                          \
         if (!vec) return launch_igemm_t<T, false, false>(a, splitk, stream);                        \
         return a.pre_scale ? launch_igemm_t<T, true, true>(a, splitk, stream) : launch_igemm_t<T, true, false>(a, splitk, stream);
+#define IE_CASE_VEC(T)                                                                              \
+    case T:                                                                                          \
+        if (!vec) return hipErrorInvalidValue;                                                       \
+        return a.pre_scale ? launch_igemm_t<T, true, true>(a, splitk, stream) : launch_igemm_t<T, true, false>(a, splitk, stream);
     switch (tile) {
         IE_CASE(0) IE_CASE(1) IE_CASE(2) IE_CASE(3) IE_CASE(4) IE_CASE(5) IE_CASE(6)
+        IE_CASE_VEC(7) IE_CASE_VEC(8) IE_CASE_VEC(9) IE_CASE_VEC(10)
         default: return hipErrorInvalidValue;
     }
 #undef IE_CASE
+#undef IE_CASE_VEC
 }
 
 hipError_t InitRasterKernels();
@@ -515,6 +556,11 @@ hipError_t InitKernels() {
     if ((e = init_igemm_t<T, false, false>()) != hipSuccess) return e;
     IE_INIT(0) IE_INIT(1) IE_INIT(2) IE_INIT(3) IE_INIT(4) IE_INIT(5) IE_INIT(6)
 #undef IE_INIT
+#define IE_INIT_VEC(T)                                                 \
+    if ((e = init_igemm_t<T, true, true>()) != hipSuccess) return e;   \
+    if ((e = init_igemm_t<T, true, false>()) != hipSuccess) return e;
+    IE_INIT_VEC(7) IE_INIT_VEC(8) IE_INIT_VEC(9) IE_INIT_VEC(10)
+#undef IE_INIT_VEC
     return InitRasterKernels();
 }
 

@@ -146,10 +146,10 @@ int choose_tile(int64_t M, int64_t N) {
     // Estimated time = rounds over the 256 CUs x tile area / tile efficiency.  Larger tiles reuse operands
     // better (higher MFMA duty); smaller ones fill the chip when M*N is small.  A lone workgroup per CU
     // cannot hide its own staging latency, so under-filled grids are charged a lower duty.
-    static const double eff[kNumIgemmTiles] = {1.00, 0.92, 0.78, 0.82, 0.62, 0.40, 0.84};
+    static const double eff[kNumIgemmBaseTiles] = {1.00, 0.92, 0.78, 0.82, 0.62, 0.40, 0.84};
     int best = -1;
     double best_cost = 0;
-    for (int t = 0; t < kNumIgemmTiles; ++t) {
+    for (int t = 0; t < kNumIgemmBaseTiles; ++t) {
         const IgemmTile& T = kIgemmTiles[t];
         if (T.bn > 32 && N <= 32) continue;             // do not waste MFMA columns on zero padding
         if (T.bn > 64 && N <= 64) continue;
@@ -705,10 +705,11 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                 else s.algo = ConvAlgo::Naive;
                 s.tile = choose_tile(M, N);
                 s.splitk = 1;
+                const int heuristic_tile = s.tile;
                 // Test / tuning overrides (read at plan time): IE_FORCE_TILE=<0..6>, IE_FORCE_ALGO=naive|scalar
                 if (const char* ft = std::getenv("IE_FORCE_TILE")) {
                     int t = std::atoi(ft);
-                    if (t >= 0 && t < kNumIgemmTiles) s.tile = t;
+                    if (t >= 0 && t < kNumIgemmTiles && (t < kNumIgemmBaseTiles || s.algo == ConvAlgo::IgemmVec)) s.tile = t;
                 }
                 if (const char* fa = std::getenv("IE_FORCE_ALGO")) {
                     std::string f = fa;
@@ -725,6 +726,8 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                         } else if (s.algo == ConvAlgo::Naive) s.algo = vec_ok ? ConvAlgo::IgemmVec : (K <= 2048 ? ConvAlgo::IgemmScalar : ConvAlgo::Naive);
                     }
                 }
+                if (s.algo != ConvAlgo::IgemmVec && s.algo != ConvAlgo::Raster3x3 && s.tile >= kNumIgemmBaseTiles)
+                    s.tile = heuristic_tile;       // K-group tiles exist for the vector path only
                 if (s.algo == ConvAlgo::Raster3x3) {
                     if (const char* fs = std::getenv("IE_FORCE_SPLITK")) {
                         int v = std::atoi(fs);
