@@ -84,7 +84,7 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run: exercise the RCCL path even at N=1
         import torch
         import torch.distributed as dist_mod
         torch.cuda.set_device(local_rank)
@@ -169,13 +169,23 @@ def main() -> None:
         dom = max(fam, key=lambda k: fam[k]["ms"])
         d = fam[dom]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        traffic, traffic_src = None, None
+        try:      # HBM bytes per launch from the committed PMC pass of the same command (rocprofv3 cannot run inside bench.py)
+            rounds = sorted(x for x in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", x, "traffic.json")))
+            if rounds:
+                traffic_src = os.path.join("profiles", rounds[-1], "traffic.json")
+                traffic = json.load(open(os.path.join(ROOT, traffic_src))).get(dom, {}).get("hbm_bytes_per_launch")
+        except Exception:  # noqa: BLE001
+            pass
         result["roofline"] = {
             "kernel": dom, "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+            "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"], 1),
             "launches_per_step": d["launches"], "flops_per_launch": round(d["flops"] / d["launches"], 1),
             "avg_launch_ms": round(d["ms"] / d["launches"], 6),
             "note": "algorithmic FLOPs (2*M*N*K summed over the family's launches of one forward) / sum of their HIP-event "
-                    "durations in an eager instrumented pass; traffic: see profiles/ (PMC pass)",
+                    "durations in an eager instrumented pass on the model's stream; traffic = (2*FETCH_SIZE + WRITE_SIZE) from a "
+                    "separate rocprofv3 --pmc pass (gfx950 FETCH_SIZE correction), family average per launch",
         }
         result["kernel_families_ms"] = {k: round(v["ms"], 4) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
         result["eager_forward_ms"] = round(sum(p["ms"] for p in prof), 4)

@@ -15,6 +15,7 @@ for f in files:
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         disp[k].add(r["Dispatch_Id"])
 names = sorted({c for v in agg.values() for c in v})
-print("kernel,dispatches," + ",".join(names))
+w = csv.writer(sys.stdout)          # kernel names contain commas (template arguments): quote them
+w.writerow(["kernel", "dispatches"] + names)
 for k in sorted(agg, key=lambda k: -sum(agg[k].values())):
-    print(k + "," + str(len(disp[k])) + "," + ",".join(f"{agg[k].get(c, 0):.0f}" for c in names))
+    w.writerow([k, len(disp[k])] + [f"{agg[k].get(c, 0):.0f}" for c in names])

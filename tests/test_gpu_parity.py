@@ -280,6 +280,41 @@ def test_device_resident_path_matches_host_path(densenet):
     assert ptr and nbytes > 30e6
 
 
+def test_weight_blob_aliases_engine_memory_for_rccl(densenet):
+    """The N>1 launcher broadcasts the packed weights IN PLACE: the torch tensor handed to RCCL must alias the engine's HBM."""
+    import torch
+    from gpu_ai_inference_server_amd import sharding
+    ptr, nbytes = B.GetWeightBlob(densenet)
+    t = torch.as_tensor(sharding._DevicePtr(ptr, nbytes), device="cuda")
+    assert t.data_ptr() == ptr and t.numel() == nbytes and t.dtype == torch.uint8
+    host = np.empty(nbytes, np.uint8)
+    B.CopyToHost(densenet, host, ptr)
+    assert sharding.blob_checksum(host) == sharding.blob_checksum(t.cpu().numpy())
+    # a write through the torch view is visible to the engine (what a broadcast on a non-root rank does) -- restore afterwards
+    first = t[:16].clone()
+    t[:16] = 7
+    torch.cuda.synchronize()
+    B.CopyToHost(densenet, host, ptr)
+    assert (host[:16] == 7).all()
+    t[:16] = first
+    torch.cuda.synchronize()
+
+
+def test_bench_under_torchrun_single_rank(tmp_path):
+    """bench.py through the driver's launch contract (torch.distributed.run, nccl = RCCL) on the one GPU of this box:
+    process-group init, in-place weight broadcast, barrier, all-reduce(MAX) of the elapsed time."""
+    import json
+    import sys
+    env = dict(os.environ, IE_BENCH_MODEL_ROOT=str(tmp_path))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29617", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
+                        "--cpu-sample", "0", "--no-hostpath"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["value"] > 1000 and d["scaling"] == "weak" and d["roofline"]["bound"] == "mfma"
+
+
 def test_concurrent_infer_load_unload(mgr):
     """gin serves each request on its own goroutine: concurrent ModelInfer on one handle plus registry traffic."""
     mgr.LoadModel("mini_densenet")
