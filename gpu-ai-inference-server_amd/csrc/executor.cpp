@@ -96,6 +96,12 @@ DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id) 
                 tune_cache_[key] = {t, sp};
         }
     }
+    if (const char* ns = std::getenv("IE_STREAMS")) sub_streams_ = std::max(1, std::min(8, std::atoi(ns)));
+    for (int i = 1; i < sub_streams_; ++i) {
+        hipStream_t st = nullptr;
+        check(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
+        side_streams_.push_back(st);
+    }
     pinned_bytes_ = kChunk * kSlots;
     check(hipHostMalloc(&pinned_, pinned_bytes_, hipHostMallocDefault), "hipHostMalloc");
 }
@@ -103,15 +109,62 @@ DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id) 
 DeviceModel::~DeviceModel() {
     (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize(stream_);
-    for (auto& kv : plans_) {
-        if (kv.second->graph_exec) (void)hipGraphExecDestroy(kv.second->graph_exec);
-        for (float* b : kv.second->buffers) if (b) (void)hipFree(b);
-        if (kv.second->workspace) (void)hipFree(kv.second->workspace);
-        if (kv.second->counters) (void)hipFree(kv.second->counters);
-    }
+    for (auto& kv : plans_) FreeInstance(*kv.second);
+    for (auto st : side_streams_) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     if (d_weights_) (void)hipFree(d_weights_);
     if (pinned_) (void)hipHostFree(pinned_);
     if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void DeviceModel::FreeInstance(PlanInstance& pi) {
+    for (auto& sub : pi.subs) FreeInstance(*sub);
+    if (pi.graph_exec) (void)hipGraphExecDestroy(pi.graph_exec);
+    for (size_t i = 0; i < pi.buffers.size(); ++i)
+        if (pi.buffers[i] && pi.owned[i]) (void)hipFree(pi.buffers[i]);
+    if (pi.workspace) (void)hipFree(pi.workspace);
+    if (pi.counters) (void)hipFree(pi.counters);
+    if (pi.done) (void)hipEventDestroy(pi.done);
+    if (pi.fork) (void)hipEventDestroy(pi.fork);
+}
+
+// Plan + allocate one instance.  io_only: allocate just the graph input/output buffers (parent of sub-batch instances).
+void DeviceModel::BuildInstance(PlanInstance& pi, const std::vector<std::vector<int64_t>>& shapes, bool io_only) {
+    pi.plan = BuildPlan(*model_, shapes);
+    pi.stream = stream_;
+    if (!d_weights_) {
+        weight_floats_ = pi.plan.weights.size();
+        check(hipMalloc(reinterpret_cast<void**>(&d_weights_), std::max<size_t>(weight_floats_, 4) * sizeof(float)), "hipMalloc(weights)");
+        device_bytes_ += weight_floats_ * sizeof(float);
+        check(hipMemcpy(d_weights_, pi.plan.weights.data(), weight_floats_ * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy(weights)");
+    } else if (pi.plan.weights.size() != weight_floats_) {
+        throw std::runtime_error("internal error: weight blob layout depends on the input shape");
+    }
+    std::vector<float>().swap(pi.plan.weights);   // the host copy of the blob is only needed for the first upload
+    std::vector<char> is_io(pi.plan.buffer_floats.size(), 0);
+    for (auto& d : pi.plan.inputs) is_io[size_t(d.view.buf)] = 1;
+    for (auto& d : pi.plan.outputs) is_io[size_t(d.view.buf)] = 1;
+    pi.buffers.assign(pi.plan.buffer_floats.size(), nullptr);
+    pi.owned.assign(pi.plan.buffer_floats.size(), 0);
+    for (size_t i = 0; i < pi.plan.buffer_floats.size(); ++i) {
+        if (io_only && !is_io[i]) continue;
+        float* p = nullptr;
+        size_t bytes = size_t(std::max<int64_t>(pi.plan.buffer_floats[i], 4)) * sizeof(float);
+        check(hipMalloc(reinterpret_cast<void**>(&p), bytes), "hipMalloc(activations)");
+        check(hipMemsetAsync(p, 0, bytes, stream_), "hipMemset(activations)");
+        device_bytes_ += bytes;
+        pi.buffers[i] = p;
+        pi.owned[i] = 1;
+    }
+    if (!io_only) {   // split-K scratch: slabs + per-tile arrival counters (tile-padded slabs need up to 2x the exact S*M*N)
+        pi.workspace_floats = std::max<int64_t>(2 * pi.plan.workspace_floats, kTuneWorkspaceFloats);
+        size_t bytes = size_t(pi.workspace_floats) * sizeof(float);
+        check(hipMalloc(reinterpret_cast<void**>(&pi.workspace), bytes), "hipMalloc(workspace)");
+        device_bytes_ += bytes;
+        if (!two_pass_splitk_) {
+            check(hipMalloc(reinterpret_cast<void**>(&pi.counters), kNumCounters * sizeof(int)), "hipMalloc(counters)");
+            check(hipMemsetAsync(pi.counters, 0, kNumCounters * sizeof(int), stream_), "hipMemset(counters)");
+        }
+    }
 }
 
 PlanInstance& DeviceModel::Prepare(const std::vector<std::vector<int64_t>>& shapes) {
@@ -121,54 +174,70 @@ PlanInstance& DeviceModel::Prepare(const std::vector<std::vector<int64_t>>& shap
     if (it != plans_.end()) { current_ = it->second.get(); return *current_; }
 
     check(hipSetDevice(device_), "hipSetDevice");
-    auto pi = std::make_unique<PlanInstance>();
-    pi->plan = BuildPlan(*model_, shapes);
-    if (!d_weights_) {
-        weight_floats_ = pi->plan.weights.size();
-        check(hipMalloc(reinterpret_cast<void**>(&d_weights_), std::max<size_t>(weight_floats_, 4) * sizeof(float)), "hipMalloc(weights)");
-        device_bytes_ += weight_floats_ * sizeof(float);
-        check(hipMemcpy(d_weights_, pi->plan.weights.data(), weight_floats_ * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy(weights)");
-    } else if (pi->plan.weights.size() != weight_floats_) {
-        throw std::runtime_error("internal error: weight blob layout depends on the input shape");
-    }
-    // the host copy of the blob is only needed for the first upload
-    std::vector<float>().swap(pi->plan.weights);
-    for (int64_t nfl : pi->plan.buffer_floats) {
-        float* p = nullptr;
-        size_t bytes = size_t(std::max<int64_t>(nfl, 4)) * sizeof(float);
-        check(hipMalloc(reinterpret_cast<void**>(&p), bytes), "hipMalloc(activations)");
-        check(hipMemsetAsync(p, 0, bytes, stream_), "hipMemset(activations)");
-        device_bytes_ += bytes;
-        pi->buffers.push_back(p);
-    }
-    {   // split-K scratch: slabs + per-tile arrival counters (tile-padded slabs need up to 2x the exact S*M*N)
-        pi->workspace_floats = std::max<int64_t>(2 * pi->plan.workspace_floats, kTuneWorkspaceFloats);
-        size_t bytes = size_t(pi->workspace_floats) * sizeof(float);
-        check(hipMalloc(reinterpret_cast<void**>(&pi->workspace), bytes), "hipMalloc(workspace)");
-        device_bytes_ += bytes;
-        if (!two_pass_splitk_) {
-            check(hipMalloc(reinterpret_cast<void**>(&pi->counters), kNumCounters * sizeof(int)), "hipMalloc(counters)");
-            check(hipMemsetAsync(pi->counters, 0, kNumCounters * sizeof(int), stream_), "hipMemset(counters)");
-        }
-    }
-    check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
-    if (autotune_) Autotune(*pi);
+    // Sub-batch split: every graph input shares the leading batch dimension and it divides evenly.
+    int nsub = sub_streams_;
+    int64_t batch = shapes.empty() || shapes[0].empty() ? 0 : shapes[0][0];
+    for (auto& s : shapes) if (s.empty() || s[0] != batch) nsub = 1;
+    if (batch < 2 * nsub || batch % nsub != 0) nsub = 1;
 
-    if (use_graph_) {
-        hipGraph_t graph = nullptr;
-        check(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
-        try {
-            RunSteps(*pi, nullptr, nullptr);
-        } catch (...) {
-            (void)hipStreamEndCapture(stream_, &graph);
-            if (graph) (void)hipGraphDestroy(graph);
-            throw;
+    auto pi = std::make_unique<PlanInstance>();
+    try {
+        BuildInstance(*pi, shapes, nsub > 1);
+        if (nsub > 1) {
+            for (auto& d : pi->plan.outputs) if (d.dims.empty() || d.dims[0] != batch) nsub = 1;
         }
-        check(hipStreamEndCapture(stream_, &graph), "hipStreamEndCapture");
-        hipError_t e = hipGraphInstantiate(&pi->graph_exec, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        check(e, "hipGraphInstantiate");
-        pi->graph_ready = true;
+        if (nsub > 1) {
+            std::vector<std::vector<int64_t>> sub_shapes = shapes;
+            for (auto& s : sub_shapes) s[0] = batch / nsub;
+            check(hipEventCreateWithFlags(&pi->fork, hipEventDisableTiming), "hipEventCreate");
+            for (int k = 0; k < nsub; ++k) {
+                auto sub = std::make_unique<PlanInstance>();
+                BuildInstance(*sub, sub_shapes, false);
+                sub->stream = k == 0 ? stream_ : side_streams_[size_t(k - 1)];
+                check(hipEventCreateWithFlags(&sub->done, hipEventDisableTiming), "hipEventCreate");
+                // alias the sub instance's I/O buffers to slices of the parent's full-size buffers
+                auto alias = [&](const std::vector<IoDesc>& sub_io, const std::vector<IoDesc>& full_io) {
+                    for (size_t i = 0; i < sub_io.size(); ++i) {
+                        const size_t sb = size_t(sub_io[i].view.buf), fb = size_t(full_io[i].view.buf);
+                        if (sub->buffers[sb] && sub->owned[sb]) (void)hipFree(sub->buffers[sb]);
+                        sub->buffers[sb] = pi->buffers[fb] + int64_t(k) * sub_io[i].view.numel();
+                        sub->owned[sb] = 0;
+                    }
+                };
+                alias(sub->plan.inputs, pi->plan.inputs);
+                alias(sub->plan.outputs, pi->plan.outputs);
+                pi->subs.push_back(std::move(sub));
+            }
+        } else if (pi->workspace == nullptr) {
+            // nsub fell back to 1 after an io_only build: rebuild fully
+            FreeInstance(*pi);
+            pi = std::make_unique<PlanInstance>();
+            BuildInstance(*pi, shapes, false);
+        }
+        check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+        if (autotune_) {
+            if (pi->subs.empty()) Autotune(*pi);
+            for (auto& sub : pi->subs) Autotune(*sub);
+        }
+        if (use_graph_) {
+            hipGraph_t graph = nullptr;
+            check(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+            try {
+                RunSteps(*pi, nullptr, nullptr);
+            } catch (...) {
+                (void)hipStreamEndCapture(stream_, &graph);
+                if (graph) (void)hipGraphDestroy(graph);
+                throw;
+            }
+            check(hipStreamEndCapture(stream_, &graph), "hipStreamEndCapture");
+            hipError_t e = hipGraphInstantiate(&pi->graph_exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            check(e, "hipGraphInstantiate");
+            pi->graph_ready = true;
+        }
+    } catch (...) {
+        FreeInstance(*pi);
+        throw;
     }
     current_ = pi.get();
     plans_[key] = std::move(pi);
@@ -198,9 +267,9 @@ void DeviceModel::Autotune(PlanInstance& pi) {
             float best = 1e30f;
             int best_tile = s.tile, best_split = s.splitk;
             auto time_trial = [&](const Step& trial) {
-                LaunchStep(pi, trial);                       // warm
+                LaunchStep(pi, trial, stream_);              // warm
                 check(hipEventRecord(e0, stream_), "hipEventRecord");
-                for (int r = 0; r < 3; ++r) LaunchStep(pi, trial);
+                for (int r = 0; r < 3; ++r) LaunchStep(pi, trial, stream_);
                 check(hipEventRecord(e1, stream_), "hipEventRecord");
                 check(hipEventSynchronize(e1), "hipEventSynchronize");
                 float ms = 0;
@@ -270,7 +339,7 @@ void DeviceModel::Autotune(PlanInstance& pi) {
     }
 }
 
-void DeviceModel::LaunchStep(const PlanInstance& pi, const Step& s) {
+void DeviceModel::LaunchStep(const PlanInstance& pi, const Step& s, hipStream_t stream_) {
     const float* wb = d_weights_;
     auto wp = [&](int64_t off) -> const float* { return off >= 0 ? wb + off : nullptr; };
     switch (s.kind) {
@@ -342,13 +411,34 @@ static std::string kernel_label(const Step& s) {
 }
 
 void DeviceModel::RunSteps(PlanInstance& pi, std::vector<StepTiming>* timings, std::vector<hipEvent_t>* events) {
+    (void)timings;
+    if (!pi.subs.empty() && !events) {
+        // fork: side streams wait for everything enqueued on the main stream so far; join: main waits for every sub-batch
+        check(hipEventRecord(pi.fork, stream_), "hipEventRecord");
+        for (auto& sub : pi.subs) {
+            if (sub->stream != stream_) check(hipStreamWaitEvent(sub->stream, pi.fork, 0), "hipStreamWaitEvent");
+            for (const Step& s : sub->plan.steps) LaunchStep(*sub, s, sub->stream);
+            if (sub->stream != stream_) check(hipEventRecord(sub->done, sub->stream), "hipEventRecord");
+        }
+        for (auto& sub : pi.subs)
+            if (sub->stream != stream_) check(hipStreamWaitEvent(stream_, sub->done, 0), "hipStreamWaitEvent");
+        return;
+    }
+    // single instance, or instrumented pass (sub-batches one after the other on the main stream, an event after every launch)
     size_t k = 0;
     if (events) check(hipEventRecord((*events)[k++], stream_), "hipEventRecord");
-    for (const Step& s : pi.plan.steps) {
-        LaunchStep(pi, s);
-        if (events) check(hipEventRecord((*events)[k++], stream_), "hipEventRecord");
+    if (pi.subs.empty()) {
+        for (const Step& s : pi.plan.steps) {
+            LaunchStep(pi, s, stream_);
+            if (events) check(hipEventRecord((*events)[k++], stream_), "hipEventRecord");
+        }
+    } else {
+        for (auto& sub : pi.subs)
+            for (const Step& s : sub->plan.steps) {
+                LaunchStep(*sub, s, stream_);
+                if (events) check(hipEventRecord((*events)[k++], stream_), "hipEventRecord");
+            }
     }
-    (void)timings;
 }
 
 void DeviceModel::Enqueue(PlanInstance& pi) {
@@ -364,15 +454,18 @@ void DeviceModel::Synchronize() {
 
 std::vector<StepTiming> DeviceModel::Profile(PlanInstance& pi, int iters) {
     check(hipSetDevice(device_), "hipSetDevice");
-    const size_t ns = pi.plan.steps.size();
+    std::vector<const Step*> steps;
+    if (pi.subs.empty()) for (const Step& s : pi.plan.steps) steps.push_back(&s);
+    else for (auto& sub : pi.subs) for (const Step& s : sub->plan.steps) steps.push_back(&s);
+    const size_t ns = steps.size();
     std::vector<hipEvent_t> ev(ns + 1);
     for (auto& e : ev) check(hipEventCreate(&e), "hipEventCreate");
     std::vector<StepTiming> out(ns);
     for (size_t i = 0; i < ns; ++i) {
-        out[i].name = pi.plan.steps[i].name;
-        out[i].kernel = kernel_label(pi.plan.steps[i]);
-        out[i].flops = pi.plan.steps[i].flops;
-        out[i].bytes = pi.plan.steps[i].bytes;
+        out[i].name = steps[i]->name;
+        out[i].kernel = kernel_label(*steps[i]);
+        out[i].flops = steps[i]->flops;
+        out[i].bytes = steps[i]->bytes;
     }
     try {
         RunSteps(pi, nullptr, nullptr);   // warm

@@ -23,7 +23,16 @@ struct StepTiming {
 
 struct PlanInstance {
     Plan plan;
-    std::vector<float*> buffers;       // device activation buffers (plan.buffer_floats)
+    std::vector<float*> buffers;       // device activation buffers (plan.buffer_floats); aliased I/O entries are not owned
+    std::vector<char> owned;           // buffers[i] was hipMalloc'ed by this instance
+    // Sub-batch streams: a batch of B images can run as S independent sub-batches of B/S on S streams inside ONE
+    // hipGraph (fork/join).  Layers whose output grid cannot fill 256 CUs (dense blocks 3-4 at batch 32) are latency
+    // bound, so two half-batches in flight together use the idle CUs.  The parent instance then owns only the
+    // full-size input/output buffers; each sub instance owns its activations and aliases slices of the parent's I/O.
+    std::vector<std::unique_ptr<PlanInstance>> subs;
+    hipStream_t stream = nullptr;      // stream this instance's kernels are enqueued on
+    hipEvent_t done = nullptr;         // join event (sub instances on side streams)
+    hipEvent_t fork = nullptr;         // parent only
     float* workspace = nullptr;        // split-K slabs
     int64_t workspace_floats = 0;
     int* counters = nullptr;           // split-K arrival counters (zero between launches)
@@ -63,10 +72,12 @@ public:
 
 private:
     void RunSteps(PlanInstance& pi, std::vector<StepTiming>* timings, std::vector<hipEvent_t>* events);
+    void BuildInstance(PlanInstance& pi, const std::vector<std::vector<int64_t>>& shapes, bool io_only);
+    void FreeInstance(PlanInstance& pi);
     // Exhaustive (tile, split-K) search per distinct conv shape, timed with HIP events on the model's stream; the
     // MI355X counterpart of the reference's cudnn_conv_algo_search = Exhaustive (model.cpp:886).
     void Autotune(PlanInstance& pi);
-    void LaunchStep(const PlanInstance& pi, const Step& s);
+    void LaunchStep(const PlanInstance& pi, const Step& s, hipStream_t stream);
 
     std::shared_ptr<const OnnxModel> model_;
     int device_ = 0;
@@ -76,6 +87,8 @@ private:
     size_t device_bytes_ = 0;
     bool use_graph_ = true;
     bool autotune_ = true;
+    int sub_streams_ = 1;              // IE_STREAMS: sub-batches run concurrently per forward
+    std::vector<hipStream_t> side_streams_;
     bool two_pass_splitk_ = true;      // IE_SPLITK_IN_LAUNCH=1 selects the in-launch combine instead of the reduce kernel
     std::map<std::vector<int64_t>, std::pair<int, int>> tune_cache_;   // conv signature -> (tile, splitk)
     std::map<std::vector<int64_t>, std::unique_ptr<PlanInstance>> plans_;

@@ -21,6 +21,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "igemm_tiles.h"
 #include "kernels.h"
@@ -57,7 +60,9 @@ __device__ __forceinline__ bool splitk_combine(f32x16 (&acc)[TM][TN], float* __r
         *lds_word = __hip_atomic_fetch_add(counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    if (*lds_word != nsplit - 1) return false;
+    const int ticket = *lds_word;
+    __syncthreads();                                            // the word lives in reusable LDS: everyone reads it before anyone moves on
+    if (ticket != nsplit - 1) return false;
     if (tid == 0) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // drop this CU's stale L1 lines of the other slabs
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -107,16 +112,16 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_igemm_kernel(const Con
     const int wm_i = wave / WN, wn_i = wave % WN;
     const int r = lane & 31, hh = lane >> 5;
 
-    // XCD-aware bijective remap: blocks b, b+8, b+16.. share an XCD; give each XCD a contiguous tile range.
-    int tile_m, tile_n;
-    {
-        const int bid = blockIdx.x;
-        const int q = num_tiles >> 3, rem = num_tiles & 7, xcd = bid & 7;
-        const int swz = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
-        tile_n = swz % tiles_n;
-        tile_m = swz / tiles_n;
-    }
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    // XCD-aware bijective remap of a linear tile index: indices i, i+8, i+16.. share an XCD (workgroups are dealt
+    // round-robin over the 8 XCDs and the persistent stride is a multiple of 8), so each XCD owns a contiguous tile range.
+    auto tile_origin = [&](int lin, int& m0_, int& n0_, int& id_) {
+        const int q = num_tiles >> 3, rem = num_tiles & 7, xcd = lin & 7;
+        const int swz = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (lin >> 3);
+        const int tn = swz % tiles_n, tm = swz / tiles_n;
+        m0_ = tm * BM;
+        n0_ = tn * BN;
+        id_ = tm * tiles_n + tn;
+    };
 
     const int Cin = a.in.c, H = a.in.h, W = a.in.w;
     const int OH = a.out.h, OW = a.out.w, Cout = a.out.c;
@@ -125,14 +130,18 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_igemm_kernel(const Con
     const float* __restrict__ in = a.in.p;
     const float* __restrict__ wgt = a.w;
     const bool has_pre = a.pre_scale != nullptr;
+    const int nsplit = gridDim.y, split = blockIdx.y;   // split-K over workgroups: grid.y slices the K-tiles
 
     f32x16 acc[TM][TN];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    };
+    zero_acc();
 
     // Fragment reads are software-pipelined by hand: the ds_read_b128s of step kk+1 are issued BEFORE the MFMAs of step kk
     // (two register sets), otherwise every group of MFMAs starts with an exposed LDS round trip.
@@ -167,8 +176,63 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_igemm_kernel(const Con
         }
     };
 
-    // K-range of this workgroup (split-K: grid.y slices the K-tiles; partial sums go to a workspace slab)
-    const int nsplit = gridDim.y, split = blockIdx.y;
+    // ---- epilogue of one finished tile ----------------------------------------------------------------------
+    // nsplit > 1: either the in-launch combine (only the last-arriving K-slice of a tile stores) or, with the two-pass
+    // fallback, every slice stores its raw slab [split][M][Cout] for splitk_reduce_kernel.
+    auto epilogue = [&](const int m0, const int n0, const int tile_id) {
+        if (nsplit > 1 && a.counters != nullptr) {
+            if (!splitk_combine<TM, TN, NT>(acc, a.workspace, a.counters, tile_id, num_tiles, split, nsplit, tid, reinterpret_cast<int*>(smem)))
+                return;
+        }
+        const bool partial = nsplit > 1 && a.counters == nullptr;
+        float* __restrict__ out = partial ? a.workspace + int64_t(split) * M * Cout : a.out.p;
+        const int opitch = partial ? Cout : int(a.out.sw);
+        // finish the values in place first, so the stores below issue back-to-back from distinct registers
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn_i * TN + j) * 32 + r;
+            const float bv = (!partial && a.bias != nullptr && n < Cout) ? a.bias[n] : 0.f;
+            const bool do_relu = a.relu && !partial;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float v = acc[i][j][e] + bv;
+                    acc[i][j][e] = do_relu ? fmaxf(v, 0.f) : v;
+                }
+        }
+        const bool full = (m0 + BM <= M) && (n0 + BN <= Cout);     // workgroup-uniform: interior tiles skip the guards
+        if (full) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + (wn_i * TN + j) * 32 + r;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    float* o = out + int64_t(m0 + (wm_i * TM + i) * 32 + 4 * hh) * opitch + n;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[((e & 3) + 8 * (e >> 2)) * opitch] = acc[i][j][e];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + (wn_i * TN + j) * 32 + r;
+                const bool nok = n < Cout;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int mb = m0 + (wm_i * TM + i) * 32 + 4 * hh;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int m = mb + (e & 3) + 8 * (e >> 2);
+                        if (nok && m < M) out[int64_t(m) * opitch + n] = acc[i][j][e];
+                    }
+                }
+            }
+        }
+    };
+
+    int m0, n0, tile_id;
+    tile_origin(blockIdx.x, m0, n0, tile_id);
 
     if constexpr (VEC) {
         // ---- float4 staging: thread owns column-quad `c4` of rows {rw + i*ROWS_PER_PASS} ----------------
@@ -195,25 +259,28 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_igemm_kernel(const Con
 
         int poff[A_IT];                  // element offset of tap (0,0), channel c4 of this row's window
         unsigned taps[A_IT];             // bit t set: tap t of this row lies inside the image (kh*kw <= 32)
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const int m = m0 + rw + i * ROWS_PER_PASS;
-            const bool mok = m < M;
-            const int mm = mok ? m : 0;
-            const int b = mm / (OH * OW);
-            const int rem = mm - b * (OH * OW);
-            const int oy = rem / OW, ox = rem - oy * OW;
-            const int iy0 = oy * a.sh - a.pt, ix0 = ox * a.sw - a.pl;
-            poff[i] = b * int(a.in.sn) + iy0 * ish + ix0 * isw + c4;
-            unsigned msk = 0;
-            for (int ky = 0; ky < a.kh; ++ky)
-                for (int kx = 0; kx < a.kw; ++kx)
-                    if (unsigned(iy0 + ky) < unsigned(H) && unsigned(ix0 + kx) < unsigned(W)) msk |= 1u << (ky * a.kw + kx);
-            taps[i] = mok ? msk : 0u;
-        }
         int boff[B_IT];                  // element offset of (row n, k = c4) in the packed weights
+        auto setup_rows = [&](const int tm0, const int tn0) {
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) boff[i] = (n0 + rw + i * ROWS_PER_PASS) * Ktot + c4;   // rows >= Cout land out of range
+            for (int i = 0; i < A_IT; ++i) {
+                const int m = tm0 + rw + i * ROWS_PER_PASS;
+                const bool mok = m < M;
+                const int mm = mok ? m : 0;
+                const int b = mm / (OH * OW);
+                const int rem = mm - b * (OH * OW);
+                const int oy = rem / OW, ox = rem - oy * OW;
+                const int iy0 = oy * a.sh - a.pt, ix0 = ox * a.sw - a.pl;
+                poff[i] = b * int(a.in.sn) + iy0 * ish + ix0 * isw + c4;
+                unsigned msk = 0;
+                for (int ky = 0; ky < a.kh; ++ky)
+                    for (int kx = 0; kx < a.kw; ++kx)
+                        if (unsigned(iy0 + ky) < unsigned(H) && unsigned(ix0 + kx) < unsigned(W)) msk |= 1u << (ky * a.kw + kx);
+                taps[i] = mok ? msk : 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) boff[i] = (tn0 + rw + i * ROWS_PER_PASS) * Ktot + c4;   // rows >= Cout land out of range
+        };
+        setup_rows(m0, n0);
 
         f32x4 ra[A_IT], rb[B_IT];
         f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
@@ -268,49 +335,74 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_igemm_kernel(const Con
         const int nkt = kt_end - kt_begin;
         const int gb = kt_begin + int(int64_t(nkt) * grp / KG), ge = kt_begin + int(int64_t(nkt) * (grp + 1) / KG);
         const int rounds = (nkt + KG - 1) / KG;
-        if (nkt > 0) {
-            if (gb < ge) {
-                issue_loads(gb);
-                finish_store(0);
-            }
-            __syncthreads();
+        // K-tile rotation: workgroup t starts its K loop at K-tile (t mod n) and wraps around.  Row pitches of the NHWC
+        // buffers and of the packed weights are multiples of 1 KiB, so workgroups marching through K in lockstep would all
+        // hit the same few L2 / memory channels at any instant; rotating the start spreads them over all channels.
+        const int ng = ge - gb;
+        auto rot_of = [&](int id) { return ng > 1 && !(a.debug & 16) ? id % ng : 0; };
+        int rot = rot_of(tile_id);
+        auto kt_of = [&](int j, int rt) { const int x = j + rt; return gb + (x >= ng ? x - ng : x); };
+        if (ng > 0) {
+            issue_loads(kt_of(0, rot));
+            finish_store(0);
+        }
+        __syncthreads();
+        // Persistent workgroups (KG == 1): a workgroup walks tiles lin, lin + gridDim.x, ...  The operand loads of the NEXT
+        // tile's first K-tile are issued before the last MFMA block of the current tile, so neither the next tile's first
+        // HBM/L2 round trip nor the current tile's store epilogue leaves the matrix cores idle.
+        int lin = blockIdx.x;
+        int parity = 0;
+        for (;;) {
+            const int nlin = lin + int(gridDim.x);
+            const bool has_next = KG == 1 && nlin < num_tiles;
+            int nm0 = 0, nn0 = 0, nid = 0;
+            if (has_next) tile_origin(nlin, nm0, nn0, nid);
+            const int nrot = has_next ? rot_of(nid) : 0;
             for (int it = 0; it < rounds; ++it) {
-                const int kt = gb + it;
-                const int buf = it & 1;
-                const bool active = kt < ge, more = kt + 1 < ge;
-                if (more && !(a.debug & 1)) issue_loads(kt + 1);
+                const int buf = parity;
+                const bool active = it < ng, more = it + 1 < ng;
+                const bool cross = has_next && !more && active;      // last K-tile of this output tile: prefetch across the seam
+                if (!(a.debug & 1)) {
+                    if (more) issue_loads(kt_of(it + 1, rot));
+                    else if (cross) { setup_rows(nm0, nn0); issue_loads(kt_of(0, nrot)); }
+                }
                 __builtin_amdgcn_sched_barrier(0);       // loads stay ahead of the MFMA block ...
                 if (active && !(a.debug & 2)) compute(buf);
                 __builtin_amdgcn_sched_barrier(0);       // ... and their consumers stay behind it
-                if (more && !(a.debug & 4)) finish_store(buf ^ 1);
+                if ((more || cross) && !(a.debug & 4)) finish_store(buf ^ 1);
                 if (!(a.debug & 8)) __syncthreads();
+                parity ^= 1;
             }
-        }
-        if constexpr (KG > 1) {
-            // Sum the K-groups' partial tiles through LDS (each group's own staging area is free now), in group order.
-            if (grp > 0) {
+            if constexpr (KG > 1) {
+                // Sum the K-groups' partial tiles through LDS (each group's own staging area is free now), in group order.
+                if (grp > 0) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
+                        for (int j = 0; j < TN; ++j)
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) sA[((i * TN + j) * 16 + e) * NT + tid] = acc[i][j][e];
+                            for (int e = 0; e < 16; ++e) sA[((i * TN + j) * 16 + e) * NT + tid] = acc[i][j][e];
+                }
+                __syncthreads();
+                if (grp > 0) return;
+#pragma unroll
+                for (int g = 1; g < KG; ++g) {
+                    const float* p = smem + g * GROUP_LDS;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) acc[i][j][e] += p[((i * TN + j) * 16 + e) * NT + tid];
+                }
             }
-            __syncthreads();
-            if (grp > 0) return;
-#pragma unroll
-            for (int g = 1; g < KG; ++g) {
-                const float* p = smem + g * GROUP_LDS;
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) acc[i][j][e] += p[((i * TN + j) * 16 + e) * NT + tid];
-            }
+            epilogue(m0, n0, tile_id);
+            if (!has_next) break;
+            lin = nlin; m0 = nm0; n0 = nn0; tile_id = nid; rot = nrot;
+            zero_acc();
         }
     } else {
-        // ---- scalar gather staging: any Cin, any input strides (NCHW stem) ------------------------------
+        // ---- scalar gather staging: any Cin, any input strides (NCHW stem); one tile per workgroup ----------
         constexpr int ROWS_PER_PASS = NT / BK;
         constexpr int A_IT = BM / ROWS_PER_PASS, B_IT = BN / ROWS_PER_PASS;
         int64_t* const s_rbase = reinterpret_cast<int64_t*>(smem + 2 * (BM + BN) * LDP);
@@ -392,60 +484,7 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_igemm_kernel(const Con
                 __syncthreads();
             }
         }
-    }
-
-    // ---- epilogue ---------------------------------------------------------------------------------------
-    // nsplit > 1: in-launch combine; only the last-arriving K-slice of a tile continues into the store epilogue
-    // (or, with the two-pass fallback, every slice stores its raw slab [split][M][Cout] for splitk_reduce_kernel).
-    const int tile_id = tile_m * tiles_n + tile_n;
-    if (nsplit > 1 && a.counters != nullptr) {
-        if (!splitk_combine<TM, TN, NT>(acc, a.workspace, a.counters, tile_id, num_tiles, split, nsplit, tid, reinterpret_cast<int*>(smem)))
-            return;
-    }
-    const bool partial = nsplit > 1 && a.counters == nullptr;
-    float* __restrict__ out = partial ? a.workspace + int64_t(split) * M * Cout : a.out.p;
-    const int opitch = partial ? Cout : int(a.out.sw);
-    // finish the values in place first, so the stores below issue back-to-back from distinct registers
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + (wn_i * TN + j) * 32 + r;
-        const float bv = (!partial && a.bias != nullptr && n < Cout) ? a.bias[n] : 0.f;
-        const bool do_relu = a.relu && !partial;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float v = acc[i][j][e] + bv;
-                acc[i][j][e] = do_relu ? fmaxf(v, 0.f) : v;
-            }
-    }
-    const bool full = (m0 + BM <= M) && (n0 + BN <= Cout);     // workgroup-uniform: interior tiles skip the guards
-    if (full) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + (wn_i * TN + j) * 32 + r;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                float* o = out + int64_t(m0 + (wm_i * TM + i) * 32 + 4 * hh) * opitch + n;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) o[((e & 3) + 8 * (e >> 2)) * opitch] = acc[i][j][e];
-            }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + (wn_i * TN + j) * 32 + r;
-            const bool nok = n < Cout;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int mb = m0 + (wm_i * TM + i) * 32 + 4 * hh;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = mb + (e & 3) + 8 * (e >> 2);
-                    if (nok && m < M) out[int64_t(m) * opitch + n] = acc[i][j][e];
-                }
-            }
-        }
+        epilogue(m0, n0, tile_id);
     }
 }
 
@@ -461,6 +500,33 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, const int nsp
     for (int s = 0; s < nsplit; ++s) v += ws[int64_t(s) * total + idx];
     if (relu) v = fmaxf(v, 0.f);
     out[m * opitch + n] = v;
+}
+
+// Resident workgroups the chip can hold for this kernel (occupancy API x CU count), and the persistent grid derived from
+// it: never more workgroups than tiles; a multiple of 8 so the XCD-aware tile remap keeps lin % 8 == blockIdx.x % 8.
+static int PersistentSlots(const void* kernel, int block, size_t lds) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, size_t>, int> cache;
+    static int cus = 0;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = cache.find({kernel, lds});
+    if (it != cache.end()) return it->second;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, lds) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
+    return cache[{kernel, lds}] = per_cu * cus;
+}
+static int PersistentGrid(int num_tiles, int slots, int splitk) {
+    static const bool off = [] { const char* e = std::getenv("IE_NO_PERSISTENT"); return e && e[0] == '1'; }();
+    if (off) return num_tiles;
+    int g = slots / (splitk > 0 ? splitk : 1);
+    if (g < 8) g = 8;
+    g &= ~7;
+    return num_tiles < g ? num_tiles : g;
 }
 
 // Does the split-K scratch of this launch fit the workspace / counter arrays handed in by the executor?
@@ -490,8 +556,14 @@ static hipError_t launch_igemm_t(const ConvArgs& a, int splitk, hipStream_t stre
     const int num_tiles = tiles_m * tiles_n;
     if (splitk > 1 && !SplitKFits(a, splitk, num_tiles, t.bm * t.bn, M * a.out.c)) return hipErrorInvalidValue;
     if (t.kg > 1 && splitk > 1 && a.counters != nullptr) return hipErrorInvalidValue;   // in-launch combine assumes one K-group
+    int grid = num_tiles;
+    if (VEC && t.kg == 1 && !(splitk > 1 && a.counters != nullptr)) {
+        const int slots = PersistentSlots(reinterpret_cast<const void*>(&conv_igemm_kernel<t.bm, t.bn, t.wm, t.wn, t.kg, VEC, PRE>),
+                                          64 * t.wm * t.wn * t.kg, igemm_lds_bytes<T, VEC>());
+        grid = PersistentGrid(num_tiles, slots, splitk);
+    }
     conv_igemm_kernel<t.bm, t.bn, t.wm, t.wn, t.kg, VEC, PRE>
-        <<<dim3(num_tiles, splitk), dim3(64 * t.wm * t.wn * t.kg), igemm_lds_bytes<T, VEC>(), stream>>>(a, tiles_n, num_tiles);
+        <<<dim3(grid, splitk), dim3(64 * t.wm * t.wn * t.kg), igemm_lds_bytes<T, VEC>(), stream>>>(a, tiles_n, num_tiles);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || splitk == 1 || a.counters != nullptr) return e;
     const int64_t total = M * a.out.c;
