@@ -187,6 +187,10 @@ def main() -> None:
                     "durations in an eager instrumented pass on the model's stream; traffic = (2*FETCH_SIZE + WRITE_SIZE) from a "
                     "separate rocprofv3 --pmc pass (gfx950 FETCH_SIZE correction), family average per launch",
         }
+        # the tight per-layer bound  sum_l max(bytes_l / HBM peak, flops_l / fp32 MFMA peak)
+        tight_ms = sum(max(p["bytes"] / (PEAK_HBM_GBS * 1e9), p["flops"] / (PEAK_FP32_MFMA_TFLOPS * 1e12)) for p in prof) * 1e3
+        result["roofline_model"] = {"tight_bound_ms_per_step": round(tight_ms, 4), "frac_of_tight_bound": round(tight_ms / (elapsed / args.steps * 1e3), 4),
+                                    "flops_per_step": sum(p["flops"] for p in prof), "algorithmic_bytes_per_step": sum(p["bytes"] for p in prof)}
         result["kernel_families_ms"] = {k: round(v["ms"], 4) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
         result["eager_forward_ms"] = round(sum(p["ms"] for p in prof), 4)
         # ---- full C-ABI call with host buffers (PCIe-inclusive; reported, never `value`) -----------------------

@@ -41,6 +41,50 @@ hipError_t g_kernels_err = hipSuccess;
 
 }  // namespace
 
+CopyPool::CopyPool(int helpers) {
+    for (int i = 0; i < helpers; ++i) threads_.emplace_back([this, i] { Worker(i); });
+}
+CopyPool::~CopyPool() {
+    { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
+    cv_.notify_all();
+    for (auto& t : threads_) t.join();
+}
+void CopyPool::Worker(int idx) {
+    uint64_t seen = 0;
+    for (;;) {
+        char* d; const char* s; size_t n; size_t parts;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return stop_ || generation_ != seen; });
+            if (stop_) return;
+            seen = generation_;
+            d = dst_; s = src_; n = n_; parts = threads_.size() + 1;
+        }
+        const size_t per = (n / parts + 63) & ~size_t(63);
+        const size_t b = std::min(n, per * size_t(idx + 1)), e = std::min(n, per * size_t(idx + 2));
+        if (e > b) std::memcpy(d + b, s + b, e - b);
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            if (--pending_ == 0) done_cv_.notify_one();
+        }
+    }
+}
+void CopyPool::Copy(void* dst, const void* src, size_t n) {
+    if (threads_.empty() || n < (size_t(1) << 20)) { std::memcpy(dst, src, n); return; }
+    const size_t parts = threads_.size() + 1;
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        dst_ = static_cast<char*>(dst); src_ = static_cast<const char*>(src); n_ = n;
+        pending_ = int(threads_.size());
+        ++generation_;
+    }
+    cv_.notify_all();
+    const size_t per = (n / parts + 63) & ~size_t(63);
+    std::memcpy(dst, src, std::min(n, per));      // the caller copies slice 0
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [&] { return pending_ == 0; });
+}
+
 int HipDeviceCount() {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
@@ -101,6 +145,11 @@ DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id) 
         hipStream_t st = nullptr;
         check(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
         side_streams_.push_back(st);
+    }
+    {
+        int helpers = 3;
+        if (const char* h = std::getenv("IE_COPY_THREADS")) helpers = std::max(0, std::min(15, std::atoi(h) - 1));
+        copy_pool_ = std::make_unique<CopyPool>(helpers);
     }
     pinned_bytes_ = kChunk * kSlots;
     check(hipHostMalloc(&pinned_, pinned_bytes_, hipHostMallocDefault), "hipHostMalloc");
@@ -192,7 +241,16 @@ PlanInstance& DeviceModel::Prepare(const std::vector<std::vector<int64_t>>& shap
             check(hipEventCreateWithFlags(&pi->fork, hipEventDisableTiming), "hipEventCreate");
             for (int k = 0; k < nsub; ++k) {
                 auto sub = std::make_unique<PlanInstance>();
-                BuildInstance(*sub, sub_shapes, false);
+                try {
+                    BuildInstance(*sub, sub_shapes, false);
+                } catch (const std::exception&) {
+                    // e.g. the model fixes its batch dimension: run the whole batch as one instance
+                    FreeInstance(*sub);
+                    for (auto& s2 : pi->subs) FreeInstance(*s2);
+                    pi->subs.clear();
+                    nsub = 1;
+                    break;
+                }
                 sub->stream = k == 0 ? stream_ : side_streams_[size_t(k - 1)];
                 check(hipEventCreateWithFlags(&sub->done, hipEventDisableTiming), "hipEventCreate");
                 // alias the sub instance's I/O buffers to slices of the parent's full-size buffers
@@ -208,7 +266,8 @@ PlanInstance& DeviceModel::Prepare(const std::vector<std::vector<int64_t>>& shap
                 alias(sub->plan.outputs, pi->plan.outputs);
                 pi->subs.push_back(std::move(sub));
             }
-        } else if (pi->workspace == nullptr) {
+        }
+        if (nsub == 1 && pi->workspace == nullptr) {
             // nsub fell back to 1 after an io_only build: rebuild fully
             FreeInstance(*pi);
             pi = std::make_unique<PlanInstance>();
@@ -506,7 +565,7 @@ void DeviceModel::InferHost(PlanInstance& pi, const std::vector<const void*>& in
                 const size_t nb = std::min(kChunk, have - off);
                 if (slot_used[slot]) check(hipEventSynchronize(slot_ev[slot]), "hipEventSynchronize");
                 char* stage = static_cast<char*>(pinned_) + size_t(slot) * kChunk;
-                std::memcpy(stage, static_cast<const char*>(inputs[i]) + off, nb);
+                copy_pool_->Copy(stage, static_cast<const char*>(inputs[i]) + off, nb);
                 check(hipMemcpyAsync(dst + off, stage, nb, hipMemcpyHostToDevice, stream_), "hipMemcpyAsync(H2D)");
                 check(hipEventRecord(slot_ev[slot], stream_), "hipEventRecord");
                 slot_used[slot] = true;

@@ -367,7 +367,9 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_igemm_kernel(const Con
                     else if (cross) { setup_rows(nm0, nn0); issue_loads(kt_of(0, nrot)); }
                 }
                 __builtin_amdgcn_sched_barrier(0);       // loads stay ahead of the MFMA block ...
+                if (a.debug & 32) __builtin_amdgcn_s_setprio(1);
                 if (active && !(a.debug & 2)) compute(buf);
+                if (a.debug & 32) __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);       // ... and their consumers stay behind it
                 if ((more || cross) && !(a.debug & 4)) finish_store(buf ^ 1);
                 if (!(a.debug & 8)) __syncthreads();

@@ -354,3 +354,87 @@ def test_c_replay_harness_on_gpu(model_repo, engine_lib):
     vals = [float(v) for v in [l for l in r.stdout.splitlines() if l.startswith("OUTPUT ")][0].split()[1:]]
     np.testing.assert_allclose(vals, [-1.6748662, 2.0709436], rtol=2e-6)   # ones(1,3) probe (test/onnx_test.cpp:92), SURVEY §8c
     assert "count=1 mem=10485780" in out["CALL ModelGetStats"]
+
+
+def _random_conv_graph(rs, case):
+    """One random Conv (+ optional pre-activation BN/ReLU, bias, post BN/ReLU, concat partner) as an ONNX graph."""
+    from gpu_ai_inference_server_amd.modelgen import onnx_pb as pb
+    n = int(rs.choice([1, 2, 3, 5]))
+    k = int(rs.choice([1, 1, 3, 3, 5, 7]))
+    stride = int(rs.choice([1, 1, 2]))
+    pad = int(rs.choice([0, k // 2]))
+    cin = int(rs.choice([3, 4, 8, 12, 20, 32, 36, 64, 96]))
+    cout = int(rs.choice([1, 5, 16, 32, 40, 64, 100, 128]))
+    h = int(rs.randint(max(k, 3), 24))
+    w = int(rs.randint(max(k, 3), 24))
+    pre = bool(rs.randint(2)) and cin % 4 == 0
+    post = int(rs.randint(3))          # 0 none, 1 relu, 2 bn+relu
+    bias = bool(rs.randint(2))
+    nodes, inits = [], []
+    x = "x"
+    # a first 1x1 conv moves the tensor into the engine's NHWC world so the conv under test takes the vector path
+    w0 = (rs.randn(cin, 3, 1, 1) * 0.5).astype(np.float32)
+    inits.append(pb.tensor("w0", w0))
+    nodes.append(pb.node("Conv", ["x", "w0"], ["h0"], "c0", [pb.attr_ints("kernel_shape", [1, 1])]))
+    x = "h0"
+    if pre:
+        for nm, v in (("g", 1 + 0.1 * rs.randn(cin)), ("b", 0.1 * rs.randn(cin)), ("m", 0.1 * rs.randn(cin)), ("v", 0.5 + rs.rand(cin))):
+            inits.append(pb.tensor("pre_" + nm, v.astype(np.float32)))
+        nodes.append(pb.node("BatchNormalization", [x, "pre_g", "pre_b", "pre_m", "pre_v"], ["p0"], "prebn", [pb.attr_float("epsilon", 1e-5)]))
+        nodes.append(pb.node("Relu", ["p0"], ["p1"], "prerelu"))
+        x = "p1"
+    wt = (rs.randn(cout, cin, k, k) * np.sqrt(2.0 / (cin * k * k))).astype(np.float32)
+    inits.append(pb.tensor("w", wt))
+    ins = [x, "w"]
+    if bias:
+        inits.append(pb.tensor("bvec", (0.2 * rs.randn(cout)).astype(np.float32)))
+        ins.append("bvec")
+    nodes.append(pb.node("Conv", ins, ["y0"], "conv", [pb.attr_ints("kernel_shape", [k, k]), pb.attr_ints("pads", [pad] * 4),
+                                                       pb.attr_ints("strides", [stride, stride])]))
+    y = "y0"
+    if post == 2:
+        for nm, v in (("g", 1 + 0.1 * rs.randn(cout)), ("b", 0.1 * rs.randn(cout)), ("m", 0.1 * rs.randn(cout)), ("v", 0.5 + rs.rand(cout))):
+            inits.append(pb.tensor("post_" + nm, v.astype(np.float32)))
+        nodes.append(pb.node("BatchNormalization", [y, "post_g", "post_b", "post_m", "post_v"], ["y1"], "postbn", [pb.attr_float("epsilon", 1e-5)]))
+        y = "y1"
+    if post >= 1:
+        nodes.append(pb.node("Relu", [y], ["y2"], "postrelu"))
+        y = "y2"
+    oh = (h + 2 * pad - k) // stride + 1
+    ow = (w + 2 * pad - k) // stride + 1
+    # concat the result behind a strided copy of itself: exercises channel-offset epilogues into a wider buffer
+    nodes.append(pb.node("Concat", [y, y], ["out"], "cat", [pb.attr_int("axis", 1)]))
+    g = pb.graph(f"rand{case}", nodes, inits, [pb.value_info("x", [n, 3, h, w])], [pb.value_info("out", [n, 2 * cout, oh, ow])])
+    return pb.model(g), (n, 3, h, w), (n, 2 * cout, oh, ow), dict(k=k, stride=stride, pad=pad, cin=cin, cout=cout, h=h, w=w, pre=pre, post=post, bias=bias)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_conv_graphs_vs_oracle(tmp_path, seed):
+    """Seeded random convolutions (kernel 1..7, stride 1/2, ragged channels, with/without the fused BN+ReLU prologue /
+    epilogue, duplicated into a Concat) through every algorithm choice the planner/autotuner can make, against the oracle."""
+    rs = np.random.RandomState(1000 + seed)
+    modes = [dict(), dict(IE_AUTOTUNE="0"), dict(IE_FORCE_ALGO="raster"), dict(IE_FORCE_ALGO="igemm", IE_FORCE_TILE=str(7 + seed)),
+             dict(IE_FORCE_ALGO="scalar", IE_FORCE_TILE=str(seed)), dict(IE_FORCE_ALGO="igemm", IE_FORCE_SPLITK="3", IE_FORCE_TILE=str(seed + 2))]
+    worst = 0.0
+    for case in range(8):
+        mb, ishape, oshape, desc = _random_conv_graph(rs, case)
+        d = models.write_repo(str(tmp_path), f"r{seed}_{case}", mb)
+        om = O.load_model(mb)
+        x = rs.rand(*ishape).astype(np.float32)
+        ref = O.run(om, {"x": x}, dtype=np.float64)["out"]
+        env = modes[case % len(modes)]
+        os.environ.update(env)
+        try:
+            m = B.CreateModel(d, "r")
+            try:
+                y, dims = infer(m, "", "x", x, "out", oshape)
+            finally:
+                m.Destroy()
+        finally:
+            for k_ in env:
+                os.environ.pop(k_, None)
+        assert dims == list(oshape)
+        e = rel_err(y, ref)
+        worst = max(worst, e)
+        assert e < RTOL, (desc, env, e)
+    print(f"seed {seed}: worst rel err {worst:.2e}")
