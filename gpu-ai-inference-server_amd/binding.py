@@ -69,7 +69,7 @@ ABI_SYMBOLS = [
     "ModelLoad", "ModelUnload",
 ]
 EXT_SYMBOLS = ["EngineDescribeModel", "EnginePrepare", "EngineRunPrepared", "EngineSynchronize", "EngineGetStream",
-               "EngineProfile", "EngineGetWeightBlob", "EngineMemcpy", "EngineMfmaPeak", "EngineVectorAdd"]
+               "EngineProfile", "EngineGetWeightBlob", "EngineMemcpy", "EngineMfmaPeak", "EngineGetBatcherStats", "EngineVectorAdd"]
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -113,6 +113,7 @@ def lib() -> C.CDLL:
             "EngineVectorAdd": (C.c_bool, [vp, vp, vp, C.c_size_t, ep]),
             "EngineMemcpy": (C.c_bool, [vp, vp, vp, C.c_size_t, C.c_int, ep]),
             "EngineMfmaPeak": (C.c_double, [C.c_int, C.c_int, C.c_int]),
+            "EngineGetBatcherStats": (C.c_bool, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)   # AttributeError here = symbol missing from the .so
@@ -510,6 +511,12 @@ def CopyToHost(model: Model, dst: np.ndarray, src_dev: int) -> None:
 
 def MfmaPeak(nacc: int = 4, blocks_per_cu: int = 1, iters: int = 2000) -> float:
     return float(lib().EngineMfmaPeak(nacc, blocks_per_cu, iters))
+
+
+def BatcherStats(model: Model) -> dict:
+    b, r, m = C.c_int64(0), C.c_int64(0), C.c_int(0)
+    lib().EngineGetBatcherStats(model.handle, C.byref(b), C.byref(r), C.byref(m))
+    return {"device_batches": int(b.value), "coalesced_requests": int(r.value), "max_batch": int(m.value)}
 
 
 def VectorAdd(a: np.ndarray, b: np.ndarray) -> np.ndarray:

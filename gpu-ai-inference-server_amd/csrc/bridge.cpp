@@ -12,6 +12,9 @@
 //   * no CPU execution provider: without a HIP device Load fails loudly
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <regex>
 #include <cstdlib>
 #include <cstring>
 #include <filesystem>
@@ -68,8 +71,34 @@ struct ModelObj {
     std::atomic<int64_t> inference_count{0}, total_ns{0}, last_ns{0};
     std::atomic<size_t> memory_usage_bytes{0};
 
+    // ---- dynamic request batcher: honours the reference's inert max_batch_size / dynamic_batching fields
+    // (model.h:63,70-71).  Concurrent ModelInfer calls (one per gin goroutine) are coalesced into ONE device batch and the
+    // results are scattered back per caller.  Enabled by IE_DYNAMIC_BATCH=<max rows> or config.json
+    // {"dynamic_batching": true, "max_batch_size": N}; only for graphs whose inputs/outputs have a symbolic batch axis.
+    struct Pending {
+        std::vector<const void*> in_ptr;
+        std::vector<size_t> in_bytes;
+        std::vector<std::vector<int64_t>> shapes;
+        TensorData* outputs = nullptr;
+        int num_outputs = 0;
+        int64_t rows = 0;
+        bool done = false, ok = false;
+        std::string err;
+    };
+    int cfg_max_batch = 0;        // from ModelCreate's ModelConfig {dynamic_batching, max_batch_size}
+    int max_batch = 0;            // 0/1 = batching off
+    int batch_window_us = 200;
+    bool batchable = false;       // set at Load: symbolic batch axis on every graph input and output
+    std::mutex bmu;
+    std::condition_variable bcv;
+    std::deque<Pending*> queue;
+    bool leader_active = false;
+    std::atomic<int64_t> device_batches{0}, coalesced_requests{0};
+
     bool Load();      // model.cpp:503-548 + 825-871
     void Unload();    // model.cpp:618-648
+    void Execute(std::vector<Pending*>& batch);   // runs one device batch for these callers (takes `mu`)
+    void RunBatched(Pending& req);                // leader/follower coalescing
 };
 
 bool ModelObj::Load() {
@@ -114,6 +143,25 @@ bool ModelObj::Load() {
                 for (auto& vi : inf.inputs) input_names.push_back(vi.name);
                 for (auto& vi : inf.outputs) output_names.push_back(vi.name);
                 memory_usage_bytes = inf.memory_usage_bytes;   // reference's estimate formula, model.cpp:979-1035
+                batchable = !inf.inputs.empty();
+                for (auto& vi : inf.inputs) if (vi.dims.empty() || vi.dims[0] > 0) batchable = false;
+                for (auto& vi : inf.outputs) if (vi.dims.empty() || vi.dims[0] > 0) batchable = false;
+                {   // batching knobs: environment first, then the two config.json keys the reference carries but never reads
+                    max_batch = cfg_max_batch;
+                    if (const char* e = std::getenv("IE_DYNAMIC_BATCH")) max_batch = std::atoi(e);
+                    else {
+                        std::ifstream cf(path + "/config.json");
+                        if (cf) {
+                            std::stringstream ss; ss << cf.rdbuf();
+                            const std::string txt = ss.str();
+                            std::smatch mm;
+                            const bool dyn = std::regex_search(txt, std::regex("\"dynamic_batching\"\\s*:\\s*true"));
+                            if (dyn && std::regex_search(txt, mm, std::regex("\"max_batch_size\"\\s*:\\s*(\\d+)"))) max_batch = std::stoi(mm[1]);
+                        }
+                    }
+                    if (const char* e = std::getenv("IE_BATCH_WINDOW_US")) batch_window_us = std::max(0, std::atoi(e));
+                    if (max_batch > 4096) max_batch = 4096;
+                }
                 onnx = parsed;
                 info = std::move(inf);
                 dev = std::move(dm);
@@ -281,6 +329,7 @@ ModelHandle ModelCreate(const char* model_path, ModelType type, const ModelConfi
         obj->device_id = device_id;
         obj->name = config->name ? config->name : "";
         obj->version = config->version ? config->version : "1";
+        if (config->dynamic_batching && config->max_batch_size > 1) obj->cfg_max_batch = config->max_batch_size;
         for (int i = 0; i < config->num_inputs; ++i)
             if (config->input_names && config->input_names[i]) obj->input_names.push_back(config->input_names[i]);
         for (int i = 0; i < config->num_outputs; ++i)
@@ -323,83 +372,187 @@ bool ModelInfer(ModelHandle handle, const TensorData* inputs, int num_inputs, Te
     if (!M.loaded.load()) { set_error(error, "Model not loaded"); return false; }
     if (!inputs || num_inputs <= 0 || !outputs || num_outputs <= 0) { set_error(error, "Invalid parameters"); return false; }
     try {
-        std::lock_guard<std::mutex> g(M.mu);
-        if (!M.loaded.load() || !M.dev) { set_error(error, "Model not loaded"); return false; }
-        auto failv = [&](const std::string& msg) { M.last_error = msg; set_error(error, msg); return false; };
-
-        // ---- ValidateInputs (model.cpp:734-794): count, then names ----
-        const auto& gin = M.info.inputs;
-        if (size_t(num_inputs) != gin.size())
-            return failv("Expected " + std::to_string(gin.size()) + " inputs, got " + std::to_string(num_inputs));
-        for (int i = 0; i < num_inputs; ++i) {
-            const std::string nm = inputs[i].name ? inputs[i].name : "";
-            bool known = false;
-            for (auto& vi : gin) if (vi.name == nm) known = true;
-            if (!known) return failv("Unexpected input name: " + nm);
-        }
-        // From here on the reference counts the call in its statistics even when it fails (model.cpp:572-612).
-        const auto t0 = std::chrono::steady_clock::now();
-        bool ok = false;
-        std::string err;
-        do {
+        ModelObj::Pending req;
+        bool batched = false;
+        {
+            std::lock_guard<std::mutex> g(M.mu);
+            if (!M.loaded.load() || !M.dev) { set_error(error, "Model not loaded"); return false; }
+            auto failv = [&](const std::string& msg) { M.last_error = msg; set_error(error, msg); return false; };
+            // ---- ValidateInputs (model.cpp:734-794): count, then names ----
+            const auto& gin = M.info.inputs;
+            if (size_t(num_inputs) != gin.size())
+                return failv("Expected " + std::to_string(gin.size()) + " inputs, got " + std::to_string(num_inputs));
+            for (int i = 0; i < num_inputs; ++i) {
+                const std::string nm = inputs[i].name ? inputs[i].name : "";
+                bool known = false;
+                for (auto& vi : gin) if (vi.name == nm) known = true;
+                if (!known) return failv("Unexpected input name: " + nm);
+            }
             // ---- InferONNX (model.cpp:1158-1328): order inputs by graph index ----
-            std::vector<const void*> in_ptr(gin.size(), nullptr);
-            std::vector<size_t> in_bytes(gin.size(), 0);
-            std::vector<std::vector<int64_t>> shapes(gin.size());
+            req.in_ptr.assign(gin.size(), nullptr);
+            req.in_bytes.assign(gin.size(), 0);
+            req.shapes.assign(gin.size(), {});
+            req.outputs = outputs;
+            req.num_outputs = num_outputs;
             std::vector<char> provided(gin.size(), 0);
-            bool bad = false;
-            for (int i = 0; i < num_inputs && !bad; ++i) {
+            for (int i = 0; i < num_inputs && req.err.empty(); ++i) {
                 const TensorData& t = inputs[i];
                 const std::string nm = t.name ? t.name : "";
                 for (size_t k = 0; k < gin.size(); ++k) {
                     if (gin[k].name != nm) continue;
-                    if (t.data_type != DATATYPE_FLOAT32) { err = "Unsupported data type for input: " + nm; bad = true; break; }
+                    if (t.data_type != DATATYPE_FLOAT32) { req.err = "Unsupported data type for input: " + nm; break; }
                     provided[k] = 1;
-                    shapes[k].clear();
-                    if (t.shape.dims && t.shape.num_dims > 0) shapes[k].assign(t.shape.dims, t.shape.dims + t.shape.num_dims);
-                    in_ptr[k] = (t.data && t.data_size > 0) ? t.data : nullptr;
-                    in_bytes[k] = in_ptr[k] ? t.data_size : 0;
+                    req.shapes[k].clear();
+                    if (t.shape.dims && t.shape.num_dims > 0) req.shapes[k].assign(t.shape.dims, t.shape.dims + t.shape.num_dims);
+                    req.in_ptr[k] = (t.data && t.data_size > 0) ? t.data : nullptr;
+                    req.in_bytes[k] = req.in_ptr[k] ? t.data_size : 0;
                 }
             }
-            if (bad) break;
-            for (size_t k = 0; k < gin.size(); ++k)
-                if (!provided[k]) { err = "Required input tensor not provided: " + gin[k].name; bad = true; break; }
-            if (bad) break;
-            try {
-                ie::PlanInstance& pi = M.dev->Prepare(shapes);
-                std::vector<void*> out_ptr;
-                std::vector<size_t> out_bytes;
-                for (int i = 0; i < num_outputs; ++i) {
-                    const bool copy = outputs[i].data_type == DATATYPE_FLOAT32 && outputs[i].data && outputs[i].data_size > 0;
-                    out_ptr.push_back(copy ? outputs[i].data : nullptr);
-                    out_bytes.push_back(copy ? outputs[i].data_size : 0);
-                }
-                M.dev->InferHost(pi, in_ptr, in_bytes, out_ptr, out_bytes);
-                // outputs by index, in graph-output order (bridge:787-813)
-                for (int i = 0; i < num_outputs && size_t(i) < pi.plan.outputs.size(); ++i) {
-                    const auto& dims = pi.plan.outputs[size_t(i)].dims;
-                    const int cap = outputs[i].shape.dims ? outputs[i].shape.num_dims : 0;
-                    const int nd = int(dims.size());
-                    if (outputs[i].shape.dims) {
-                        const int nw = nd < cap ? nd : cap;     // never write past the caller's array
-                        for (int j = 0; j < nw; ++j) outputs[i].shape.dims[j] = dims[size_t(j)];
-                        outputs[i].shape.num_dims = nw;
-                    }
-                }
-                ok = true;
-            } catch (const std::exception& e) {
-                err = std::string("ONNX inference error: ") + e.what();
+            for (size_t k = 0; k < gin.size() && req.err.empty(); ++k)
+                if (!provided[k]) req.err = "Required input tensor not provided: " + gin[k].name;
+            // coalescing needs one common leading (batch) dimension and the declared ranks
+            batched = req.err.empty() && M.batchable && M.max_batch > 1;
+            if (batched) {
+                req.rows = req.shapes[0].empty() ? 0 : req.shapes[0][0];
+                for (size_t k = 0; k < gin.size(); ++k)
+                    if (req.shapes[k].size() != gin[k].dims.size() || req.shapes[k][0] != req.rows) batched = false;
+                if (req.rows <= 0 || req.rows >= M.max_batch) batched = false;
             }
-        } while (false);
+            if (!batched) req.rows = 0;     // rows > 0 marks a request that may be padded / coalesced
+        }
+        // From here on the reference counts the call in its statistics even when it fails (model.cpp:572-612).
+        const auto t0 = std::chrono::steady_clock::now();
+        if (req.err.empty()) {
+            if (batched) M.RunBatched(req);
+            else { std::vector<ModelObj::Pending*> one{&req}; M.Execute(one); }
+        }
         const int64_t ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
         M.inference_count.fetch_add(1);
         M.total_ns.fetch_add(ns);
         M.last_ns.store(ns);
-        if (!ok) return failv(err);
+        if (!req.ok) {
+            { std::lock_guard<std::mutex> g(M.mu); M.last_error = req.err; }
+            set_error(error, req.err);
+            return false;
+        }
         return true;
     } catch (const std::exception& e) { set_error(error, e.what()); return false; }
     catch (...) { set_error(error, "unknown error"); return false; }
 }
+
+}  // extern "C"
+
+namespace {
+
+// outputs by index, in graph-output order (bridge:787-813); never writes past the caller's dims array
+void write_out_dims(TensorData* outputs, int num_outputs, const std::vector<ie::IoDesc>& odesc, int64_t rows) {
+    for (int i = 0; i < num_outputs && size_t(i) < odesc.size(); ++i) {
+        std::vector<int64_t> dims = odesc[size_t(i)].dims;
+        if (rows > 0 && !dims.empty()) dims[0] = rows;
+        const int cap = outputs[i].shape.dims ? outputs[i].shape.num_dims : 0;
+        const int nd = int(dims.size());
+        if (outputs[i].shape.dims) {
+            const int nw = nd < cap ? nd : cap;
+            for (int j = 0; j < nw; ++j) outputs[i].shape.dims[j] = dims[size_t(j)];
+            outputs[i].shape.num_dims = nw;
+        }
+    }
+}
+
+void ModelObj::Execute(std::vector<Pending*>& batch) {
+    std::lock_guard<std::mutex> g(mu);
+    auto fail_all = [&](const std::string& msg) { for (auto* r : batch) { r->ok = false; r->err = msg; } };
+    if (!loaded.load() || !dev) { fail_all("Model not loaded"); return; }
+    try {
+        if (batch.size() == 1 && !(batchable && max_batch > 1 && batch[0]->rows > 0)) {
+            Pending& r = *batch[0];
+            ie::PlanInstance& pi = dev->Prepare(r.shapes);
+            std::vector<void*> out_ptr;
+            std::vector<size_t> out_bytes;
+            for (int i = 0; i < r.num_outputs; ++i) {
+                const bool copy = r.outputs[i].data_type == DATATYPE_FLOAT32 && r.outputs[i].data && r.outputs[i].data_size > 0;
+                out_ptr.push_back(copy ? r.outputs[i].data : nullptr);
+                out_bytes.push_back(copy ? r.outputs[i].data_size : 0);
+            }
+            dev->InferHost(pi, r.in_ptr, r.in_bytes, out_ptr, out_bytes);
+            write_out_dims(r.outputs, r.num_outputs, pi.plan.outputs, 0);
+            r.ok = true;
+            return;
+        }
+        // ---- coalesced batch: rows of all callers back to back, padded up to a power-of-two bucket so only a handful of
+        //      plans / hipGraphs ever exist ----
+        int64_t total = 0;
+        for (auto* r : batch) total += r->rows;
+        int64_t bucket = 1;
+        while (bucket < total) bucket <<= 1;
+        if (bucket > max_batch && total <= max_batch) bucket = max_batch;
+        std::vector<std::vector<int64_t>> shapes = batch[0]->shapes;
+        for (auto& sh : shapes) sh[0] = bucket;
+        ie::PlanInstance& pi = dev->Prepare(shapes);
+        std::vector<std::vector<ie::DeviceModel::InSeg>> in(pi.plan.inputs.size());
+        std::vector<std::vector<ie::DeviceModel::OutSeg>> out(pi.plan.outputs.size());
+        int64_t row0 = 0;
+        for (auto* r : batch) {
+            for (size_t k = 0; k < pi.plan.inputs.size(); ++k) {
+                const size_t row_bytes = size_t(pi.plan.inputs[k].view.numel() / bucket) * sizeof(float);
+                in[k].push_back({r->in_ptr[k], r->in_bytes[k], size_t(r->rows) * row_bytes, size_t(row0) * row_bytes});
+            }
+            for (int j = 0; j < r->num_outputs && size_t(j) < pi.plan.outputs.size(); ++j) {
+                const TensorData& o = r->outputs[j];
+                if (o.data_type != DATATYPE_FLOAT32 || !o.data || o.data_size == 0) continue;
+                const size_t row_bytes = size_t(pi.plan.outputs[size_t(j)].view.numel() / bucket) * sizeof(float);
+                out[size_t(j)].push_back({o.data, o.data_size, size_t(r->rows) * row_bytes, size_t(row0) * row_bytes});
+            }
+            row0 += r->rows;
+        }
+        dev->InferHostSegments(pi, in, out);
+        device_batches.fetch_add(1);
+        coalesced_requests.fetch_add(int64_t(batch.size()));
+        for (auto* r : batch) {
+            write_out_dims(r->outputs, r->num_outputs, pi.plan.outputs, r->rows);
+            r->ok = true;
+        }
+    } catch (const std::exception& e) {
+        fail_all(std::string("ONNX inference error: ") + e.what());
+    }
+}
+
+void ModelObj::RunBatched(Pending& req) {
+    std::unique_lock<std::mutex> lk(bmu);
+    queue.push_back(&req);
+    bcv.notify_all();                                  // a waiting leader re-checks whether its batch is full
+    while (!req.done) {
+        if (leader_active) { bcv.wait(lk); continue; }
+        leader_active = true;                          // this caller drives the next device batch
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(batch_window_us);
+        auto queued_rows = [&] { int64_t n = 0; for (auto* r : queue) n += r->rows; return n; };
+        while (queued_rows() < max_batch && bcv.wait_until(lk, deadline) != std::cv_status::timeout) {}
+        std::vector<Pending*> batch;
+        int64_t rows = 0;
+        for (auto it = queue.begin(); it != queue.end();) {
+            Pending* r = *it;
+            bool compatible = batch.empty();
+            if (!compatible) {
+                compatible = rows + r->rows <= max_batch;
+                for (size_t k = 0; k < r->shapes.size() && compatible; ++k)
+                    compatible = std::equal(r->shapes[k].begin() + 1, r->shapes[k].end(), batch[0]->shapes[k].begin() + 1,
+                                            batch[0]->shapes[k].end());
+            }
+            if (compatible) { batch.push_back(r); rows += r->rows; it = queue.erase(it); }
+            else ++it;
+        }
+        lk.unlock();
+        Execute(batch);
+        lk.lock();
+        for (auto* r : batch) r->done = true;
+        leader_active = false;
+        bcv.notify_all();
+    }
+}
+
+}  // namespace
+
+extern "C" {
 
 ModelMetadata* ModelGetMetadata(ModelHandle handle) {
     if (!handle) return nullptr;
@@ -615,6 +768,15 @@ bool EngineMemcpy(ModelHandle handle, void* dst, const void* src, size_t bytes, 
 double EngineMfmaPeak(int nacc, int blocks_per_cu, int iters) {
     if (ie::HipDeviceCount() <= 0) return -1.0;
     try { return ie::MfmaPeakTflops(nacc, blocks_per_cu, iters); } catch (...) { return -1.0; }
+}
+
+bool EngineGetBatcherStats(ModelHandle handle, int64_t* device_batches, int64_t* coalesced_requests, int* max_batch) {
+    if (!handle) return false;
+    ModelObj& M = *handle->model;
+    if (device_batches) *device_batches = M.device_batches.load();
+    if (coalesced_requests) *coalesced_requests = M.coalesced_requests.load();
+    if (max_batch) *max_batch = (M.batchable && M.max_batch > 1) ? M.max_batch : 0;
+    return true;
 }
 
 bool EngineVectorAdd(const float* a, const float* b, float* result, size_t n, ErrorMessage* error) {

@@ -1,6 +1,7 @@
 #include "executor.h"
 
 #include <algorithm>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -327,13 +328,17 @@ void DeviceModel::Autotune(PlanInstance& pi) {
             int best_tile = s.tile, best_split = s.splitk;
             auto time_trial = [&](const Step& trial) {
                 LaunchStep(pi, trial, stream_);              // warm
-                check(hipEventRecord(e0, stream_), "hipEventRecord");
-                for (int r = 0; r < 3; ++r) LaunchStep(pi, trial, stream_);
-                check(hipEventRecord(e1, stream_), "hipEventRecord");
-                check(hipEventSynchronize(e1), "hipEventSynchronize");
-                float ms = 0;
-                check(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime");
-                return ms;
+                float best_ms = 1e30f;
+                for (int rep = 0; rep < 2; ++rep) {          // best of two timed triples: robust against one-off hiccups
+                    check(hipEventRecord(e0, stream_), "hipEventRecord");
+                    for (int r = 0; r < 3; ++r) LaunchStep(pi, trial, stream_);
+                    check(hipEventRecord(e1, stream_), "hipEventRecord");
+                    check(hipEventSynchronize(e1), "hipEventSynchronize");
+                    float ms = 0;
+                    check(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime");
+                    best_ms = std::min(best_ms, ms);
+                }
+                return best_ms;
             };
             // LDS-window kernel for 3x3/s1/p1 convs without an activation prologue
             if (s.algo == ConvAlgo::IgemmVec && s.kh == 3 && s.kw == 3 && s.sh == 1 && s.sw == 1 && s.pt == 1 && s.pl == 1 && s.pb == 1 &&
@@ -548,6 +553,20 @@ std::vector<StepTiming> DeviceModel::Profile(PlanInstance& pi, int iters) {
 
 void DeviceModel::InferHost(PlanInstance& pi, const std::vector<const void*>& inputs, const std::vector<size_t>& in_bytes,
                             const std::vector<void*>& outputs, const std::vector<size_t>& out_bytes) {
+    std::vector<std::vector<InSeg>> in(pi.plan.inputs.size());
+    for (size_t i = 0; i < pi.plan.inputs.size(); ++i) {
+        const size_t need = size_t(pi.plan.inputs[i].view.numel()) * sizeof(float);
+        in[i].push_back({inputs[i], inputs[i] ? std::min(in_bytes[i], need) : 0, need, 0});
+    }
+    std::vector<std::vector<OutSeg>> out(pi.plan.outputs.size());
+    for (size_t i = 0; i < outputs.size() && i < pi.plan.outputs.size(); ++i) {
+        if (!outputs[i] || out_bytes[i] == 0) continue;
+        out[i].push_back({outputs[i], out_bytes[i], size_t(pi.plan.outputs[i].view.numel()) * sizeof(float), 0});
+    }
+    InferHostSegments(pi, in, out);
+}
+
+void DeviceModel::InferHostSegments(PlanInstance& pi, const std::vector<std::vector<InSeg>>& in, const std::vector<std::vector<OutSeg>>& out) {
     check(hipSetDevice(device_), "hipSetDevice");
     hipEvent_t slot_ev[kSlots];
     for (auto& e : slot_ev) check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
@@ -556,39 +575,62 @@ void DeviceModel::InferHost(PlanInstance& pi, const std::vector<const void*>& in
     auto fail_cleanup = [&] { for (auto& e : slot_ev) (void)hipEventDestroy(e); };
     try {
         // ---- H2D: caller memory -> pinned ring -> device, CPU copy of chunk k+1 overlaps the DMA of chunk k ----
-        for (size_t i = 0; i < pi.plan.inputs.size(); ++i) {
+        for (size_t i = 0; i < pi.plan.inputs.size() && i < in.size(); ++i) {
             const View& v = pi.plan.inputs[i].view;
-            char* dst = reinterpret_cast<char*>(pi.buffers[size_t(v.buf)]);
-            const size_t need = size_t(v.numel()) * sizeof(float);
-            const size_t have = inputs[i] ? std::min(in_bytes[i], need) : 0;
-            for (size_t off = 0; off < have; off += kChunk) {
-                const size_t nb = std::min(kChunk, have - off);
-                if (slot_used[slot]) check(hipEventSynchronize(slot_ev[slot]), "hipEventSynchronize");
-                char* stage = static_cast<char*>(pinned_) + size_t(slot) * kChunk;
-                copy_pool_->Copy(stage, static_cast<const char*>(inputs[i]) + off, nb);
-                check(hipMemcpyAsync(dst + off, stage, nb, hipMemcpyHostToDevice, stream_), "hipMemcpyAsync(H2D)");
-                check(hipEventRecord(slot_ev[slot], stream_), "hipEventRecord");
-                slot_used[slot] = true;
-                slot = (slot + 1) % kSlots;
+            char* base = reinterpret_cast<char*>(pi.buffers[size_t(v.buf)]);
+            for (const InSeg& sg : in[i]) {
+                char* dst = base + sg.dev_off;
+                const size_t have = sg.host ? std::min(sg.have, sg.need) : 0;
+                for (size_t off = 0; off < have; off += kChunk) {
+                    const size_t nb = std::min(kChunk, have - off);
+                    if (slot_used[slot]) check(hipEventSynchronize(slot_ev[slot]), "hipEventSynchronize");
+                    char* stage = static_cast<char*>(pinned_) + size_t(slot) * kChunk;
+                    copy_pool_->Copy(stage, static_cast<const char*>(sg.host) + off, nb);
+                    check(hipMemcpyAsync(dst + off, stage, nb, hipMemcpyHostToDevice, stream_), "hipMemcpyAsync(H2D)");
+                    check(hipEventRecord(slot_ev[slot], stream_), "hipEventRecord");
+                    slot_used[slot] = true;
+                    slot = (slot + 1) % kSlots;
+                }
+                if (have < sg.need) check(hipMemsetAsync(dst + have, 0, sg.need - have, stream_), "hipMemsetAsync");
             }
-            if (have < need) check(hipMemsetAsync(dst + have, 0, need - have, stream_), "hipMemsetAsync");
         }
         Enqueue(pi);
-        // ---- D2H -------------------------------------------------------------------------------------------
-        for (size_t i = 0; i < outputs.size() && i < pi.plan.outputs.size(); ++i) {
-            if (!outputs[i] || out_bytes[i] == 0) continue;
-            const View& v = pi.plan.outputs[i].view;
+        // ---- D2H: one transfer per output when it fits the ring, then per-caller scatter on the host ----------
+        for (size_t j = 0; j < pi.plan.outputs.size() && j < out.size(); ++j) {
+            if (out[j].empty()) continue;
+            const View& v = pi.plan.outputs[j].view;
             const char* src = reinterpret_cast<const char*>(pi.buffers[size_t(v.buf)]);
-            const size_t produced = size_t(v.numel()) * sizeof(float);
-            const size_t nbytes = std::min(out_bytes[i], produced);
-            for (size_t off = 0; off < nbytes; off += kChunk * kSlots) {
-                const size_t nb = std::min(kChunk * kSlots, nbytes - off);
-                check(hipStreamSynchronize(stream_), "hipStreamSynchronize");     // ring is free again
-                check(hipMemcpyAsync(pinned_, src + off, nb, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(D2H)");
-                check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
-                std::memcpy(static_cast<char*>(outputs[i]) + off, pinned_, nb);
+            size_t lo = SIZE_MAX, hi = 0;
+            for (const OutSeg& sg : out[j]) {
+                const size_t nb = std::min(sg.cap, sg.need);
+                if (!nb) continue;
+                lo = std::min(lo, sg.dev_off);
+                hi = std::max(hi, sg.dev_off + nb);
             }
-            if (out_bytes[i] > nbytes) std::memset(static_cast<char*>(outputs[i]) + nbytes, 0, out_bytes[i] - nbytes);
+            if (hi > lo && hi - lo <= kChunk * kSlots) {
+                check(hipStreamSynchronize(stream_), "hipStreamSynchronize");     // ring is free again
+                check(hipMemcpyAsync(pinned_, src + lo, hi - lo, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(D2H)");
+                check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+                for (const OutSeg& sg : out[j]) {
+                    const size_t nb = std::min(sg.cap, sg.need);
+                    if (nb) std::memcpy(sg.host, static_cast<char*>(pinned_) + (sg.dev_off - lo), nb);
+                }
+            } else {
+                for (const OutSeg& sg : out[j]) {
+                    const size_t nbytes = std::min(sg.cap, sg.need);
+                    for (size_t off = 0; off < nbytes; off += kChunk * kSlots) {
+                        const size_t nb = std::min(kChunk * kSlots, nbytes - off);
+                        check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+                        check(hipMemcpyAsync(pinned_, src + sg.dev_off + off, nb, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(D2H)");
+                        check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+                        std::memcpy(static_cast<char*>(sg.host) + off, pinned_, nb);
+                    }
+                }
+            }
+            for (const OutSeg& sg : out[j]) {
+                const size_t nb = std::min(sg.cap, sg.need);
+                if (sg.cap > nb) std::memset(static_cast<char*>(sg.host) + nb, 0, sg.cap - nb);
+            }
         }
         check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
     } catch (...) {

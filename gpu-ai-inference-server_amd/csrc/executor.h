@@ -84,6 +84,12 @@ public:
     // bytes and the rest of the caller buffer is zero-filled.
     void InferHost(PlanInstance& pi, const std::vector<const void*>& inputs, const std::vector<size_t>& in_bytes,
                    const std::vector<void*>& outputs, const std::vector<size_t>& out_bytes);
+    // Gather/scatter form used by the dynamic batcher: several callers' row blocks land at byte offsets of one device batch.
+    // Input segment: `have` valid bytes at `host`, zero-extended to `need` bytes, placed at `dev_off` of input k.
+    // Output segment: min(cap, need) bytes from `dev_off` of output j copied to `host`, the rest of `cap` zero-filled.
+    struct InSeg { const void* host; size_t have, need, dev_off; };
+    struct OutSeg { void* host; size_t cap, need, dev_off; };
+    void InferHostSegments(PlanInstance& pi, const std::vector<std::vector<InSeg>>& in, const std::vector<std::vector<OutSeg>>& out);
 
     hipStream_t stream() const { return stream_; }
     int device() const { return device_; }

@@ -40,6 +40,10 @@ bool EngineMemcpy(ModelHandle handle, void* dst, const void* src, size_t bytes, 
 /* Calibration microbenchmark: TFLOP/s of a register-resident v_mfma_f32_32x32x2_f32 loop with `nacc` (1, 2 or 4)
  * independent accumulator chains per wave and `blocks_per_cu` 4-wave workgroups per CU; <= 0 on error. */
 double EngineMfmaPeak(int nacc, int blocks_per_cu, int iters);
+/* Dynamic request batcher counters: device batches run, caller requests folded into them, and the active row limit
+ * (0 = batching off for this model).  Enable with IE_DYNAMIC_BATCH=<rows> or config.json {"dynamic_batching": true,
+ * "max_batch_size": N} or ModelCreate's ModelConfig fields; IE_BATCH_WINDOW_US sets the coalescing window (default 200). */
+bool EngineGetBatcherStats(ModelHandle handle, int64_t* device_batches, int64_t* coalesced_requests, int* max_batch);
 /* result = a + b on the GPU for host arrays (the reference's VectorAdd smoke test, cuda_utils.cu:59-149). */
 bool EngineVectorAdd(const float* a, const float* b, float* result, size_t n, ErrorMessage* error);
 

@@ -438,3 +438,48 @@ def test_random_conv_graphs_vs_oracle(tmp_path, seed):
         worst = max(worst, e)
         assert e < RTOL, (desc, env, e)
     print(f"seed {seed}: worst rel err {worst:.2e}")
+
+
+def test_dynamic_batcher_coalesces_concurrent_requests(densenet_repo):
+    """concurrent single-image ModelInfer calls (one per server goroutine) are folded into one device batch and the
+    logits are scattered back per caller; each caller sees exactly what it would have got alone."""
+    x = models.synthetic_input((8, 3, 224, 224), stream="batcher")
+    path = os.path.join(densenet_repo, "densenet_onnx", "1")
+    ref_m = B.CreateModel(path, "densenet_onnx")
+    assert B.BatcherStats(ref_m)["max_batch"] == 0
+    ref = np.stack([infer(ref_m, "", "data_0", x[i:i + 1], "fc6_1", [1, 1000, 1, 1])[0].reshape(1000) for i in range(8)])
+    ref_m.Destroy()
+    os.environ.update(IE_DYNAMIC_BATCH="8", IE_BATCH_WINDOW_US="200000")
+    try:
+        m = B.CreateModel(path, "densenet_onnx")
+    finally:
+        del os.environ["IE_DYNAMIC_BATCH"], os.environ["IE_BATCH_WINDOW_US"]
+    try:
+        assert B.BatcherStats(m)["max_batch"] == 8
+        infer(m, "", "data_0", x[:8], "fc6_1", [8, 1000, 1, 1])       # rows == max_batch bypasses the batcher; warms the B=8 plan
+        out = [None] * 8
+        errs = []
+
+        def call(i):
+            try:
+                y, dims = infer(m, "", "data_0", x[i:i + 1], "fc6_1", [1, 1000, 1, 1])
+                assert dims == [1, 1000, 1, 1]
+                out[i] = y.reshape(1000)
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+
+        before = B.BatcherStats(m)
+        ts = [threading.Thread(target=call, args=(i,)) for i in range(8)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert not errs, errs
+        after = B.BatcherStats(m)
+        assert after["coalesced_requests"] - before["coalesced_requests"] == 8
+        assert after["device_batches"] - before["device_batches"] < 8          # several callers shared a device batch
+        assert rel_err(np.stack(out), ref) < 2e-5
+        assert m.GetStats().InferenceCount == 9
+        # a 3-image request is padded to the 4-row bucket and still returns its own 3 rows
+        y3, dims3 = infer(m, "", "data_0", x[2:5], "fc6_1", [3, 1000, 1, 1])
+        assert dims3 == [3, 1000, 1, 1] and rel_err(y3.reshape(3, 1000), ref[2:5]) < 2e-5
+    finally:
+        m.Destroy()
