@@ -370,8 +370,9 @@ void DeviceModel::Autotune(PlanInstance& pi) {
             for (int t = 0; t < kNumIgemmTiles; ++t) {
                 const IgemmTile& T = kIgemmTiles[t];
                 if ((T.bn > 32 && N <= 32) || (T.bn > 64 && N <= 64)) continue;
-                if (T.kg > 1 && (s.algo != ConvAlgo::IgemmVec || KT < 2 * T.kg)) continue;
+                if ((T.kg > 1 || T.deep) && (s.algo != ConvAlgo::IgemmVec || KT < 2 * T.kg)) continue;
                 const int64_t wgs = ((M + T.bm - 1) / T.bm) * ((N + T.bn - 1) / T.bn);
+                if (T.deep && wgs > 1024) continue;       // the deep-prefetch variants target grids that cannot fill the chip
                 for (int sp : kSplits) {
                     if (sp > 1 && T.kg > 1 && (!two_pass_splitk_ || KT / (sp * T.kg) < 2)) continue;
                     if (sp > 1 && (KT / sp < 2 || int64_t(sp) * wgs * T.bm * T.bn > pi.workspace_floats || wgs > kNumCounters ||
@@ -464,6 +465,7 @@ static std::string kernel_label(const Step& s) {
                 return "conv3x3_raster_kernel<t" + std::to_string(s.tile) + (s.splitk > 1 ? ",splitk" + std::to_string(s.splitk) : std::string()) + ">";
             return std::string("conv_igemm_kernel<") + std::to_string(kIgemmTiles[s.tile].bm) + "x" +
                    std::to_string(kIgemmTiles[s.tile].bn) + (kIgemmTiles[s.tile].kg > 1 ? "x" + std::to_string(kIgemmTiles[s.tile].kg) + "kg" : std::string()) +
+                   (kIgemmTiles[s.tile].deep ? ",deep" : "") +
                    (s.algo == ConvAlgo::IgemmVec ? ",vec" : ",scalar") +
                    (s.splitk > 1 ? ",splitk" + std::to_string(s.splitk) : std::string()) + ">";
         case StepKind::Pool: return "pool_kernel";

@@ -90,7 +90,7 @@ __device__ __forceinline__ bool splitk_combine(f32x16 (&acc)[TM][TN], float* __r
 // ------------------------------------------------------------------------------------------------
 // implicit-GEMM convolution on v_mfma_f32_32x32x2_f32
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int KG, bool VEC, bool PRE>
+template <int BM, int BN, int WM, int WN, int KG, bool VEC, bool PRE, bool DEEP>
 __global__ __launch_bounds__(64 * WM * WN * KG) void conv_igemm_kernel(const ConvArgs a, const int tiles_n, const int num_tiles) {
     constexpr int NT = 64 * WM * WN;            // threads of one K-group (they stage and compute one K-slice together)
     constexpr int BK = kIgemmBK;
@@ -282,53 +282,57 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_igemm_kernel(const Con
         };
         setup_rows(m0, n0);
 
-        f32x4 ra[A_IT], rb[B_IT];
-        f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
-        unsigned okmask = 0;
+        struct Stage {                   // one K-tile of operands in registers, between its loads and its LDS store
+            f32x4 ra[A_IT], rb[B_IT];
+            f32x4 s4, t4;
+            unsigned okmask;
+        };
+        Stage st0, st1;                  // st1 is only live in the DEEP variant
         // Phase 1: issue the loads of K-tile kt (raw values; nothing here depends on their arrival).
-        auto issue_loads = [&](int kt) {
+        auto issue_loads = [&](Stage& st, int kt) {
             const int tap = kt / cblocks;
             const int c0 = (kt - tap * cblocks) * BK;
             const int ky = tap / a.kw, kx = tap - ky * a.kw;
             const int tapoff = ky * ish + kx * isw + c0;          // scalar
             const int woff = tap * Cin + c0;                      // scalar
             const bool cok = c0 + c4 < Cin;
+            unsigned okmask = 0;
             if constexpr (PRE) {
                 const int cc = cok ? c0 + c4 : 0;
-                s4 = *reinterpret_cast<const f32x4*>(a.pre_scale + cc);
-                t4 = *reinterpret_cast<const f32x4*>(a.pre_shift + cc);
-                okmask = 0;
+                st.s4 = *reinterpret_cast<const f32x4*>(a.pre_scale + cc);
+                st.t4 = *reinterpret_cast<const f32x4*>(a.pre_shift + cc);
             }
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
                 const bool ok = cok && ((taps[i] >> tap) & 1u);
                 const unsigned off = ok ? unsigned(poff[i] + tapoff) * 4u : OOB;
-                ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0));
+                st.ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0));
                 if constexpr (PRE) okmask |= ok ? (1u << i) : 0u;
             }
 #pragma unroll
             for (int i = 0; i < B_IT; ++i) {
                 const unsigned off = cok ? unsigned(boff[i] + woff) * 4u : OOB;
-                rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0));
+                st.rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0));
             }
+            st.okmask = okmask;
         };
         // Phase 3 (after the MFMAs of the previous tile): activation prologue (+ re-zeroing of padded lanes), LDS store.
-        auto finish_store = [&](int buf) {
+        auto finish_store = [&](const Stage& st, int buf) {
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
-                f32x4 v = ra[i];
+                f32x4 v = st.ra[i];
                 if constexpr (PRE) {
-                    v = v * s4 + t4;
+                    v = v * st.s4 + st.t4;
                     if (a.pre_relu) {
                         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                     }
-                    if (!(okmask & (1u << i))) v = f32x4{0.f, 0.f, 0.f, 0.f};   // zero padding applies AFTER the activation
+                    if (!(st.okmask & (1u << i))) v = f32x4{0.f, 0.f, 0.f, 0.f};   // zero padding applies AFTER the activation
                 }
                 *reinterpret_cast<f32x4*>(sA + buf * BM * LDP + (rw + i * ROWS_PER_PASS) * LDP + c4) = v;
             }
 #pragma unroll
             for (int i = 0; i < B_IT; ++i)
-                *reinterpret_cast<f32x4*>(sB + buf * BN * LDP + (rw + i * ROWS_PER_PASS) * LDP + c4) = rb[i];
+                *reinterpret_cast<f32x4*>(sB + buf * BN * LDP + (rw + i * ROWS_PER_PASS) * LDP + c4) = st.rb[i];
         };
 
         // This K-group's contiguous share of the workgroup's K-tiles; every group runs the same number of barrier rounds.
@@ -343,37 +347,51 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_igemm_kernel(const Con
         int rot = rot_of(tile_id);
         auto kt_of = [&](int j, int rt) { const int x = j + rt; return gb + (x >= ng ? x - ng : x); };
         if (ng > 0) {
-            issue_loads(kt_of(0, rot));
-            finish_store(0);
+            issue_loads(st0, kt_of(0, rot));
+            if constexpr (DEEP) { if (ng > 1) issue_loads(st1, kt_of(1, rot)); }
+            finish_store(st0, 0);
         }
         __syncthreads();
-        // Persistent workgroups (KG == 1): a workgroup walks tiles lin, lin + gridDim.x, ...  The operand loads of the NEXT
-        // tile's first K-tile are issued before the last MFMA block of the current tile, so neither the next tile's first
+        // Persistent workgroups (KG == 1, !DEEP): a workgroup walks tiles lin, lin + gridDim.x, ...  The operand loads of the
+        // NEXT tile's first K-tile are issued before the last MFMA block of the current tile, so neither the next tile's first
         // HBM/L2 round trip nor the current tile's store epilogue leaves the matrix cores idle.
         int lin = blockIdx.x;
         int parity = 0;
         for (;;) {
             const int nlin = lin + int(gridDim.x);
-            const bool has_next = KG == 1 && nlin < num_tiles;
+            const bool has_next = KG == 1 && !DEEP && nlin < num_tiles;
             int nm0 = 0, nn0 = 0, nid = 0;
             if (has_next) tile_origin(nlin, nm0, nn0, nid);
             const int nrot = has_next ? rot_of(nid) : 0;
+            if constexpr (DEEP) {
+                // K-tile j lives in register stage j&1; tile j+2 is issued at the top of step j, tile j+1 is committed after it.
+                for (int it = 0; it < rounds; ++it) {
+                    const int buf = it & 1;
+                    const bool active = it < ng, more = it + 1 < ng, more2 = it + 2 < ng;
+                    if (it & 1) { if (more2) issue_loads(st1, kt_of(it + 2, rot)); }
+                    else        { if (more2) issue_loads(st0, kt_of(it + 2, rot)); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (active) compute(buf);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) { if (it & 1) finish_store(st0, buf ^ 1); else finish_store(st1, buf ^ 1); }
+                    __syncthreads();
+                }
+            } else {
             for (int it = 0; it < rounds; ++it) {
                 const int buf = parity;
                 const bool active = it < ng, more = it + 1 < ng;
                 const bool cross = has_next && !more && active;      // last K-tile of this output tile: prefetch across the seam
                 if (!(a.debug & 1)) {
-                    if (more) issue_loads(kt_of(it + 1, rot));
-                    else if (cross) { setup_rows(nm0, nn0); issue_loads(kt_of(0, nrot)); }
+                    if (more) issue_loads(st0, kt_of(it + 1, rot));
+                    else if (cross) { setup_rows(nm0, nn0); issue_loads(st0, kt_of(0, nrot)); }
                 }
                 __builtin_amdgcn_sched_barrier(0);       // loads stay ahead of the MFMA block ...
-                if (a.debug & 32) __builtin_amdgcn_s_setprio(1);
                 if (active && !(a.debug & 2)) compute(buf);
-                if (a.debug & 32) __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);       // ... and their consumers stay behind it
-                if ((more || cross) && !(a.debug & 4)) finish_store(buf ^ 1);
+                if ((more || cross) && !(a.debug & 4)) finish_store(st0, buf ^ 1);
                 if (!(a.debug & 8)) __syncthreads();
                 parity ^= 1;
+            }
             }
             if constexpr (KG > 1) {
                 // Sum the K-groups' partial tiles through LDS (each group's own staging area is free now), in group order.
@@ -559,12 +577,12 @@ static hipError_t launch_igemm_t(const ConvArgs& a, int splitk, hipStream_t stre
     if (splitk > 1 && !SplitKFits(a, splitk, num_tiles, t.bm * t.bn, M * a.out.c)) return hipErrorInvalidValue;
     if (t.kg > 1 && splitk > 1 && a.counters != nullptr) return hipErrorInvalidValue;   // in-launch combine assumes one K-group
     int grid = num_tiles;
-    if (VEC && t.kg == 1 && !(splitk > 1 && a.counters != nullptr)) {
-        const int slots = PersistentSlots(reinterpret_cast<const void*>(&conv_igemm_kernel<t.bm, t.bn, t.wm, t.wn, t.kg, VEC, PRE>),
+    if (VEC && t.kg == 1 && !t.deep && !(splitk > 1 && a.counters != nullptr)) {
+        const int slots = PersistentSlots(reinterpret_cast<const void*>(&conv_igemm_kernel<t.bm, t.bn, t.wm, t.wn, t.kg, VEC, PRE, (t.deep != 0)>),
                                           64 * t.wm * t.wn * t.kg, igemm_lds_bytes<T, VEC>());
         grid = PersistentGrid(num_tiles, slots, splitk);
     }
-    conv_igemm_kernel<t.bm, t.bn, t.wm, t.wn, t.kg, VEC, PRE>
+    conv_igemm_kernel<t.bm, t.bn, t.wm, t.wn, t.kg, VEC, PRE, (t.deep != 0)>
         <<<dim3(grid, splitk), dim3(64 * t.wm * t.wn * t.kg), igemm_lds_bytes<T, VEC>(), stream>>>(a, tiles_n, num_tiles);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || splitk == 1 || a.counters != nullptr) return e;
@@ -577,7 +595,7 @@ static hipError_t launch_igemm_t(const ConvArgs& a, int splitk, hipStream_t stre
 template <int T, bool VEC, bool PRE>
 static hipError_t init_igemm_t() {
     constexpr IgemmTile t = kIgemmTiles[T];
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<t.bm, t.bn, t.wm, t.wn, t.kg, VEC, PRE>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<t.bm, t.bn, t.wm, t.wn, t.kg, VEC, PRE, (t.deep != 0)>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, int(igemm_lds_bytes<T, VEC>()));
 }
 
@@ -613,7 +631,8 @@ hipError_t LaunchConvIgemm(const ConvArgs& a_in, int tile, int vec, int splitk, 
         return a.pre_scale ? launch_igemm_t<T, true, true>(a, splitk, stream) : launch_igemm_t<T, true, false>(a, splitk, stream);
     switch (tile) {
         IE_CASE(0) IE_CASE(1) IE_CASE(2) IE_CASE(3) IE_CASE(4) IE_CASE(5) IE_CASE(6)
-        IE_CASE_VEC(7) IE_CASE_VEC(8) IE_CASE_VEC(9) IE_CASE_VEC(10)
+        IE_CASE_VEC(7) IE_CASE_VEC(8) IE_CASE_VEC(9) IE_CASE_VEC(10) IE_CASE_VEC(11) IE_CASE_VEC(12) IE_CASE_VEC(13) IE_CASE_VEC(14)
+        IE_CASE_VEC(15)
         default: return hipErrorInvalidValue;
     }
 #undef IE_CASE
@@ -633,7 +652,7 @@ hipError_t InitKernels() {
 #define IE_INIT_VEC(T)                                                 \
     if ((e = init_igemm_t<T, true, true>()) != hipSuccess) return e;   \
     if ((e = init_igemm_t<T, true, false>()) != hipSuccess) return e;
-    IE_INIT_VEC(7) IE_INIT_VEC(8) IE_INIT_VEC(9) IE_INIT_VEC(10)
+    IE_INIT_VEC(7) IE_INIT_VEC(8) IE_INIT_VEC(9) IE_INIT_VEC(10) IE_INIT_VEC(11) IE_INIT_VEC(12) IE_INIT_VEC(13) IE_INIT_VEC(14) IE_INIT_VEC(15)
 #undef IE_INIT_VEC
     return InitRasterKernels();
 }

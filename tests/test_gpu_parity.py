@@ -131,7 +131,7 @@ def test_mini_graphs_vs_oracle_and_fixture(mgr, name):
         mgr.UnloadModel(name)
 
 
-@pytest.mark.parametrize("tile", range(11))
+@pytest.mark.parametrize("tile", range(16))
 @pytest.mark.parametrize("algo", ["igemm", "scalar"])
 def test_every_igemm_tile_and_loader(model_repo, tile, algo):
     """Each MFMA tile configuration x both operand loaders on graphs with ragged M / Cout / Cin tails."""
