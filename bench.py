@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_FP16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense fp16/bf16 matrix peak (no sparsity)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -71,6 +72,8 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--cpu-sample", type=int, default=8, help="images for the CPU baseline (0 = skip)")
+    ap.add_argument("--dtype", choices=["f32", "f16"], default="f32",
+                    help="f32 = the headline (BASELINE configs[1]); f16 = the fp16 precision mode (configs[2-3], use --batch 128)")
     ap.add_argument("--no-hostpath", action="store_true", help="skip the ModelInfer (PCIe-inclusive) measurement")
     args = ap.parse_args()
 
@@ -103,6 +106,7 @@ def main() -> None:
         dist.barrier()
     mdir = model_dir()
 
+    os.environ["IE_PRECISION"] = "fp16" if args.dtype == "f16" else "fp32"
     model = B.CreateModel(mdir, "densenet_onnx", device_id=local_rank)
     Bsz = args.batch
     din, dout = B.Prepare(model, [[Bsz, 3, 224, 224]], 1)
@@ -114,6 +118,7 @@ def main() -> None:
         blob = B.GetWeightBlob(model)
         sharding.broadcast_weights(dist, blob, src=0)
         torch.cuda.synchronize()
+        B.WeightsUpdated(model)                      # fp16 mode re-derives its half mirror from the broadcast blob
 
     def barrier():
         B.Synchronize(model)
@@ -150,11 +155,12 @@ def main() -> None:
     if rank == 0:
         total_images = Bsz * world * args.steps
         result = {
-            "metric": "images/sec, DenseNet-121 fp32, batch 32 per GPU, device-resident inputs (+ p50 step latency)",
+            "metric": f"images/sec, DenseNet-121 {'fp32' if args.dtype == 'f32' else 'fp16'}, batch {Bsz} per GPU, device-resident inputs (+ p50 step latency)",
             "value": round(total_images / elapsed, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "DenseNet-121 fp32 batch=32 per GPU, synthetic 3x224x224 inputs (BASELINE configs[1]); "
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"DenseNet-121 {'fp32' if args.dtype == 'f32' else 'fp16 (half activations/weights, fp32 accumulate)'} batch={Bsz} per GPU, "
+                                   f"synthetic 3x224x224 inputs (BASELINE {'configs[1]' if args.dtype == 'f32' else 'configs[2]'}); "
                                    "synthetic ONNX graph + seeded random weights (reference model file is not in the mount)",
                        "global_batch": Bsz * world, "per_gpu_batch": Bsz, "parallelism": f"dp{world} (independent batch shards)"},
             "p50_ms": round(p50, 4),
@@ -177,18 +183,25 @@ def main() -> None:
                 traffic = json.load(open(os.path.join(ROOT, traffic_src))).get(dom, {}).get("hbm_bytes_per_launch")
         except Exception:  # noqa: BLE001
             pass
-        result["roofline"] = {
-            "kernel": dom, "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
-            "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"], 1),
-            "launches_per_step": d["launches"], "flops_per_launch": round(d["flops"] / d["launches"], 1),
-            "avg_launch_ms": round(d["ms"] / d["launches"], 6),
-            "note": "algorithmic FLOPs (2*M*N*K summed over the family's launches of one forward) / sum of their HIP-event "
-                    "durations in an eager instrumented pass on the model's stream; traffic = (2*FETCH_SIZE + WRITE_SIZE) from a "
-                    "separate rocprofv3 --pmc pass (gfx950 FETCH_SIZE correction), family average per launch",
-        }
+        mfma_peak = PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_FP16_MFMA_TFLOPS
+        achieved_gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+        frac_mfma, frac_hbm = achieved / mfma_peak, achieved_gbs / PEAK_HBM_GBS
+        common = {"kernel": dom, "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
+                  "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"], 1), "launches_per_step": d["launches"],
+                  "flops_per_launch": round(d["flops"] / d["launches"], 1), "avg_launch_ms": round(d["ms"] / d["launches"], 6),
+                  "achieved_tflops": round(achieved, 3), "achieved_gbs": round(achieved_gbs, 1),
+                  "frac_of_mfma_peak": round(frac_mfma, 4), "frac_of_hbm_peak": round(frac_hbm, 4)}
+        if frac_mfma >= frac_hbm:      # the ceiling this kernel family is closer to is the one that bounds it
+            result["roofline"] = {"bound": "mfma", "achieved": round(achieved, 3), "peak": mfma_peak, "unit": "TFLOP/s", "frac": round(frac_mfma, 4)}
+        else:
+            result["roofline"] = {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(frac_hbm, 4)}
+        result["roofline"].update(common)
+        result["roofline"]["note"] = (
+            "algorithmic FLOPs (2*M*N*K) and bytes (operands once + result once) summed over the family's launches of one forward / sum "
+            "of their HIP-event durations in an eager instrumented pass on the model's stream; traffic = (2*FETCH_SIZE + WRITE_SIZE) "
+            "from a separate rocprofv3 --pmc pass (gfx950 FETCH_SIZE correction), family average per launch")
         # the tight per-layer bound  sum_l max(bytes_l / HBM peak, flops_l / fp32 MFMA peak)
-        tight_ms = sum(max(p["bytes"] / (PEAK_HBM_GBS * 1e9), p["flops"] / (PEAK_FP32_MFMA_TFLOPS * 1e12)) for p in prof) * 1e3
+        tight_ms = sum(max(p["bytes"] / (PEAK_HBM_GBS * 1e9), p["flops"] / (mfma_peak * 1e12)) for p in prof) * 1e3
         result["roofline_model"] = {"tight_bound_ms_per_step": round(tight_ms, 4), "frac_of_tight_bound": round(tight_ms / (elapsed / args.steps * 1e3), 4),
                                     "flops_per_step": sum(p["flops"] for p in prof), "algorithmic_bytes_per_step": sum(p["bytes"] for p in prof)}
         result["kernel_families_ms"] = {k: round(v["ms"], 4) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}

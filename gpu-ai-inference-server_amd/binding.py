@@ -69,7 +69,7 @@ ABI_SYMBOLS = [
     "ModelLoad", "ModelUnload",
 ]
 EXT_SYMBOLS = ["EngineDescribeModel", "EnginePrepare", "EngineRunPrepared", "EngineSynchronize", "EngineGetStream",
-               "EngineProfile", "EngineGetWeightBlob", "EngineMemcpy", "EngineMfmaPeak", "EngineGetBatcherStats", "EngineVectorAdd"]
+               "EngineProfile", "EngineGetWeightBlob", "EngineWeightsUpdated", "EngineGetPrecision", "EngineMemcpy", "EngineMfmaPeak", "EngineGetBatcherStats", "EngineVectorAdd"]
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -110,6 +110,7 @@ def lib() -> C.CDLL:
             "EngineRunPrepared": (C.c_bool, [vp, C.c_int, C.c_int, ep]), "EngineSynchronize": (C.c_bool, [vp, ep]),
             "EngineGetStream": (vp, [vp]), "EngineProfile": (vp, [vp, C.c_int, ep]),
             "EngineGetWeightBlob": (C.c_bool, [vp, ep, C.POINTER(C.c_size_t), ep]),
+            "EngineWeightsUpdated": (C.c_bool, [vp, ep]), "EngineGetPrecision": (C.c_int, [vp]),
             "EngineVectorAdd": (C.c_bool, [vp, vp, vp, C.c_size_t, ep]),
             "EngineMemcpy": (C.c_bool, [vp, vp, vp, C.c_size_t, C.c_int, ep]),
             "EngineMfmaPeak": (C.c_double, [C.c_int, C.c_int, C.c_int]),
@@ -493,6 +494,17 @@ def GetWeightBlob(model: Model):
     if not lib().EngineGetWeightBlob(model.handle, C.byref(ptr), C.byref(nbytes), C.byref(err)):
         raise RuntimeError("weight blob unavailable: " + _take_error(err))
     return int(ptr.value or 0), int(nbytes.value)
+
+
+def WeightsUpdated(model: Model) -> None:
+    """Call after rewriting the fp32 blob in place (RCCL broadcast): refreshes the half mirror of fp16 mode."""
+    err = C.c_void_p()
+    if not lib().EngineWeightsUpdated(model.handle, C.byref(err)):
+        raise RuntimeError(_take_error(err))
+
+
+def Precision(model: Model) -> str:
+    return {0: "fp32", 1: "fp16"}.get(int(lib().EngineGetPrecision(model.handle)), "unloaded")
 
 
 def CopyToDevice(model: Model, dst_dev: int, src: np.ndarray) -> None:

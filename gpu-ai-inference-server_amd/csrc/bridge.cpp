@@ -11,6 +11,7 @@
 //     output buffer (the reference overflows / leaves it uninitialised, inference_bridge.cpp:794-812)
 //   * no CPU execution provider: without a HIP device Load fails loudly
 #include <atomic>
+#include <cctype>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -128,7 +129,29 @@ bool ModelObj::Load() {
                 }
                 auto parsed = std::make_shared<ie::OnnxModel>(ie::LoadOnnxFile(file));
                 ie::ModelInfo inf = ie::DescribeModel(*parsed);
-                auto dm = std::make_unique<ie::DeviceModel>(parsed, device_id);
+                // Precision: IE_PRECISION=fp16|fp32, else config.json {"precision": "fp16"}; default fp32 (the reference's
+                // ONNX Runtime session computes in the model's own fp32).
+                ie::Precision prec = ie::Precision::F32;
+                {
+                    std::string want;
+                    if (const char* e = std::getenv("IE_PRECISION")) want = e;
+                    else {
+                        std::ifstream cf(path + "/config.json");
+                        if (cf) {
+                            std::stringstream ss; ss << cf.rdbuf();
+                            const std::string txt = ss.str();
+                            std::smatch mm;
+                            if (std::regex_search(txt, mm, std::regex("\"precision\"\\s*:\\s*\"([A-Za-z0-9]+)\""))) want = mm[1];
+                        }
+                    }
+                    for (auto& ch : want) ch = char(std::tolower(static_cast<unsigned char>(ch)));
+                    if (want == "fp16" || want == "f16" || want == "half" || want == "float16") prec = ie::Precision::F16;
+                    else if (!want.empty() && want != "fp32" && want != "f32" && want != "float32" && want != "float") {
+                        last_error = "ONNX model loading error: unsupported precision '" + want + "' (fp32 or fp16)";
+                        break;
+                    }
+                }
+                auto dm = std::make_unique<ie::DeviceModel>(parsed, device_id, prec);
                 // Plan once at load (symbolic dims -> 1): rejects unsupported graphs here, like Ort::Session's
                 // constructor does, and puts the packed weights into HBM.
                 std::vector<std::vector<int64_t>> shapes;
@@ -650,7 +673,12 @@ char* EngineDescribeModel(const char* path, int batch, ErrorMessage* error) {
                 for (size_t k = 0; k < s.size(); ++k) if (s[k] <= 0) s[k] = (k == 0 ? batch : 1);
                 shapes.push_back(s);
             }
-            o << ",\"plan\":" << ie::PlanToJson(ie::BuildPlan(m, shapes));
+            ie::Precision prec = ie::Precision::F32;       // the planner is host code: IE_PRECISION selects what to describe
+            if (const char* e = std::getenv("IE_PRECISION")) {
+                std::string w = e;
+                if (w == "fp16" || w == "f16" || w == "half") prec = ie::Precision::F16;
+            }
+            o << ",\"plan\":" << ie::PlanToJson(ie::BuildPlan(m, shapes, prec));
         }
         o << "}";
         return dup_cstr(o.str());
@@ -748,6 +776,27 @@ bool EngineGetWeightBlob(ModelHandle handle, void** d_ptr, size_t* bytes, ErrorM
         return true;
     } catch (const std::exception& e) { set_error(error, e.what()); return false; }
     catch (...) { set_error(error, "unknown error"); return false; }
+}
+
+bool EngineWeightsUpdated(ModelHandle handle, ErrorMessage* error) {
+    if (!handle) { set_error(error, "Invalid parameters"); return false; }
+    try {
+        ModelObj& M = *handle->model;
+        std::lock_guard<std::mutex> g(M.mu);
+        if (!M.loaded.load() || !M.dev) { set_error(error, "Model not loaded"); return false; }
+        M.dev->Synchronize();
+        M.dev->RefreshHalfWeights();
+        return true;
+    } catch (const std::exception& e) { set_error(error, e.what()); return false; }
+    catch (...) { set_error(error, "unknown error"); return false; }
+}
+
+int EngineGetPrecision(ModelHandle handle) {
+    if (!handle) return -1;
+    ModelObj& M = *handle->model;
+    std::lock_guard<std::mutex> g(M.mu);
+    if (!M.loaded.load() || !M.dev) return -1;
+    return int(M.dev->precision());
 }
 
 bool EngineMemcpy(ModelHandle handle, void* dst, const void* src, size_t bytes, int kind, ErrorMessage* error) {

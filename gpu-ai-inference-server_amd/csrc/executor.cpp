@@ -22,11 +22,12 @@ TensorArg make_arg(const PlanInstance& pi, const View& v) {
     TensorArg t;
     float* base = pi.buffers.at(size_t(v.buf));
     t.n = int(v.n); t.h = int(v.h); t.w = int(v.w); t.c = int(v.c);
+    t.f16 = v.f16 ? 1 : 0;
     if (v.nchw) {
         t.p = base;
         t.sw = 1; t.sh = v.w; t.sc = v.h * v.w; t.sn = v.c * v.h * v.w;
     } else {
-        t.p = base + v.c_off;
+        t.p = v.f16 ? reinterpret_cast<float*>(reinterpret_cast<char*>(base) + v.c_off * 2) : base + v.c_off;
         t.sc = 1; t.sw = v.pitch; t.sh = v.w * v.pitch; t.sn = v.h * v.w * v.pitch;
     }
     return t;
@@ -111,12 +112,16 @@ bool HipMemoryInfo(int device_id, size_t* total, size_t* free_b) {
     return ok;
 }
 
-DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id) : model_(std::move(model)), device_(device_id) {
+DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id, Precision precision)
+    : model_(std::move(model)), device_(device_id), precision_(precision) {
     int n = HipDeviceCount();
     if (n <= 0) throw std::runtime_error("No HIP device available: the MI355X engine has no CPU fallback");
     if (device_id < 0 || device_id >= n) throw std::runtime_error("Invalid device id " + std::to_string(device_id));
     check(hipSetDevice(device_), "hipSetDevice");
-    std::call_once(g_kernels_once, [] { g_kernels_err = InitKernels(); });
+    std::call_once(g_kernels_once, [] {
+        g_kernels_err = InitKernels();
+        if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsF16();
+    });
     check(g_kernels_err, "InitKernels");
     check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
     const char* ng = std::getenv("IE_DISABLE_GRAPH");
@@ -162,6 +167,7 @@ DeviceModel::~DeviceModel() {
     for (auto& kv : plans_) FreeInstance(*kv.second);
     for (auto st : side_streams_) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     if (d_weights_) (void)hipFree(d_weights_);
+    if (d_weights16_) (void)hipFree(d_weights16_);
     if (pinned_) (void)hipHostFree(pinned_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -179,13 +185,18 @@ void DeviceModel::FreeInstance(PlanInstance& pi) {
 
 // Plan + allocate one instance.  io_only: allocate just the graph input/output buffers (parent of sub-batch instances).
 void DeviceModel::BuildInstance(PlanInstance& pi, const std::vector<std::vector<int64_t>>& shapes, bool io_only) {
-    pi.plan = BuildPlan(*model_, shapes);
+    pi.plan = BuildPlan(*model_, shapes, precision_);
     pi.stream = stream_;
     if (!d_weights_) {
         weight_floats_ = pi.plan.weights.size();
         check(hipMalloc(reinterpret_cast<void**>(&d_weights_), std::max<size_t>(weight_floats_, 4) * sizeof(float)), "hipMalloc(weights)");
         device_bytes_ += weight_floats_ * sizeof(float);
         check(hipMemcpy(d_weights_, pi.plan.weights.data(), weight_floats_ * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy(weights)");
+        if (precision_ == Precision::F16) {
+            check(hipMalloc(&d_weights16_, std::max<size_t>(weight_floats_, 8) * 2), "hipMalloc(weights16)");
+            device_bytes_ += weight_floats_ * 2;
+            RefreshHalfWeights();
+        }
     } else if (pi.plan.weights.size() != weight_floats_) {
         throw std::runtime_error("internal error: weight blob layout depends on the input shape");
     }
@@ -198,7 +209,7 @@ void DeviceModel::BuildInstance(PlanInstance& pi, const std::vector<std::vector<
     for (size_t i = 0; i < pi.plan.buffer_floats.size(); ++i) {
         if (io_only && !is_io[i]) continue;
         float* p = nullptr;
-        size_t bytes = size_t(std::max<int64_t>(pi.plan.buffer_floats[i], 4)) * sizeof(float);
+        size_t bytes = size_t(std::max<int64_t>(pi.plan.buffer_floats[i], 8)) * (pi.plan.buffer_f16[i] ? 2 : 4);
         check(hipMalloc(reinterpret_cast<void**>(&p), bytes), "hipMalloc(activations)");
         check(hipMemsetAsync(p, 0, bytes, stream_), "hipMemset(activations)");
         device_bytes_ += bytes;
@@ -304,6 +315,13 @@ PlanInstance& DeviceModel::Prepare(const std::vector<std::vector<int64_t>>& shap
     return *current_;
 }
 
+void DeviceModel::RefreshHalfWeights() {
+    if (!d_weights16_) return;
+    check(hipSetDevice(device_), "hipSetDevice");
+    check(LaunchConvertF32ToF16(d_weights_, d_weights16_, int64_t(weight_floats_), stream_), "convert_f32_f16");
+    check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+}
+
 void DeviceModel::Autotune(PlanInstance& pi) {
     hipEvent_t e0, e1;
     check(hipEventCreate(&e0), "hipEventCreate");
@@ -313,10 +331,12 @@ void DeviceModel::Autotune(PlanInstance& pi) {
         for (Step& s : pi.plan.steps) {
             if (s.kind != StepKind::Conv || s.algo == ConvAlgo::Naive) continue;
             const int64_t M = s.out.n * s.out.h * s.out.w, N = s.out.c;
-            const int64_t KT = s.algo == ConvAlgo::IgemmVec ? int64_t(s.kh) * s.kw * ((s.in.c + kIgemmBK - 1) / kIgemmBK)
+            const int64_t bk = s.in.f16 ? 2 * kIgemmBK : kIgemmBK;
+            const int64_t KT = s.algo == ConvAlgo::IgemmVec ? int64_t(s.kh) * s.kw * ((s.in.c + bk - 1) / bk)
                                                            : (int64_t(s.kh) * s.kw * s.in.c + kIgemmBK - 1) / kIgemmBK;
             std::vector<int64_t> key = {M, N, s.in.c, s.kh, s.kw, s.sh, s.sw, s.pt, s.pl, s.in.h, s.in.w, s.in.pitch, s.out.pitch,
                                         s.in.nchw, int64_t(s.algo), s.pre_scale_off >= 0, s.bias_off >= 0};
+            if (s.in.f16 || s.out.f16) { key.push_back(s.in.f16); key.push_back(s.out.f16); }   // fp32 signatures keep 17 entries
             auto hit = tune_cache_.find(key);
             auto apply = [&](int enc_tile, int sp) {     // tile >= 100 encodes the raster kernel
                 if (enc_tile >= 100) { s.algo = ConvAlgo::Raster3x3; s.tile = enc_tile - 100; }
@@ -341,7 +361,7 @@ void DeviceModel::Autotune(PlanInstance& pi) {
                 return best_ms;
             };
             // LDS-window kernel for 3x3/s1/p1 convs without an activation prologue
-            if (s.algo == ConvAlgo::IgemmVec && s.kh == 3 && s.kw == 3 && s.sh == 1 && s.sw == 1 && s.pt == 1 && s.pl == 1 && s.pb == 1 &&
+            if (!s.in.f16 && !s.out.f16 && s.algo == ConvAlgo::IgemmVec && s.kh == 3 && s.kw == 3 && s.sh == 1 && s.sw == 1 && s.pt == 1 && s.pl == 1 && s.pb == 1 &&
                 s.pr == 1 && s.pre_scale_off < 0) {
                 ConvArgs probe;
                 probe.in = make_arg(pi, s.in);
@@ -371,10 +391,11 @@ void DeviceModel::Autotune(PlanInstance& pi) {
                 const IgemmTile& T = kIgemmTiles[t];
                 if ((T.bn > 32 && N <= 32) || (T.bn > 64 && N <= 64)) continue;
                 if ((T.kg > 1 || T.deep) && (s.algo != ConvAlgo::IgemmVec || KT < 2 * T.kg)) continue;
+                if (T.deep && s.in.f16) continue;         // the fp16 kernel has no deep-prefetch variants
                 const int64_t wgs = ((M + T.bm - 1) / T.bm) * ((N + T.bn - 1) / T.bn);
                 if (T.deep && wgs > 1024) continue;       // the deep-prefetch variants target grids that cannot fill the chip
                 for (int sp : kSplits) {
-                    if (sp > 1 && T.kg > 1 && (!two_pass_splitk_ || KT / (sp * T.kg) < 2)) continue;
+                    if (sp > 1 && T.kg > 1 && ((!two_pass_splitk_ && !s.in.f16) || KT / (sp * T.kg) < 2)) continue;
                     if (sp > 1 && (KT / sp < 2 || int64_t(sp) * wgs * T.bm * T.bn > pi.workspace_floats || wgs > kNumCounters ||
                                    wgs * sp > 8192 || wgs >= 1024))
                         continue;
@@ -413,6 +434,7 @@ void DeviceModel::LaunchStep(const PlanInstance& pi, const Step& s, hipStream_t 
             a.in = make_arg(pi, s.in);
             a.out = make_arg(pi, s.out);
             a.w = wp(s.w_off);
+            a.w16 = d_weights16_ && s.w_off >= 0 ? static_cast<const char*>(d_weights16_) + s.w_off * 2 : nullptr;
             a.bias = wp(s.bias_off);
             a.pre_scale = wp(s.pre_scale_off);
             a.pre_shift = wp(s.pre_shift_off);
@@ -424,6 +446,7 @@ void DeviceModel::LaunchStep(const PlanInstance& pi, const Step& s, hipStream_t 
             a.num_counters = pi.counters ? kNumCounters : 0;
             if (s.algo == ConvAlgo::Naive) check(LaunchConvNaive(a, stream_), "conv_naive");
             else if (s.algo == ConvAlgo::Raster3x3) check(LaunchConvRaster3x3(a, s.tile, s.splitk, stream_), "conv3x3_raster");
+            else if (s.in.f16) check(LaunchConvIgemmF16(a, s.tile, s.splitk, stream_), "conv_igemm_f16");
             else check(LaunchConvIgemm(a, s.tile, s.algo == ConvAlgo::IgemmVec ? 1 : 0, s.splitk, stream_), "conv_igemm");
             break;
         }
@@ -463,7 +486,7 @@ static std::string kernel_label(const Step& s) {
             if (s.algo == ConvAlgo::Naive) return "conv_naive_kernel";
             if (s.algo == ConvAlgo::Raster3x3)
                 return "conv3x3_raster_kernel<t" + std::to_string(s.tile) + (s.splitk > 1 ? ",splitk" + std::to_string(s.splitk) : std::string()) + ">";
-            return std::string("conv_igemm_kernel<") + std::to_string(kIgemmTiles[s.tile].bm) + "x" +
+            return std::string(s.in.f16 ? "conv_igemm_f16_kernel<" : "conv_igemm_kernel<") + std::to_string(kIgemmTiles[s.tile].bm) + "x" +
                    std::to_string(kIgemmTiles[s.tile].bn) + (kIgemmTiles[s.tile].kg > 1 ? "x" + std::to_string(kIgemmTiles[s.tile].kg) + "kg" : std::string()) +
                    (kIgemmTiles[s.tile].deep ? ",deep" : "") +
                    (s.algo == ConvAlgo::IgemmVec ? ",vec" : ",scalar") +

@@ -66,7 +66,7 @@ private:
 class DeviceModel {
 public:
     // Parses nothing itself: takes the decoded graph. Throws std::runtime_error (never falls back to a CPU path).
-    DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id);
+    DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id, Precision precision = Precision::F32);
     ~DeviceModel();
     DeviceModel(const DeviceModel&) = delete;
     DeviceModel& operator=(const DeviceModel&) = delete;
@@ -94,6 +94,9 @@ public:
     hipStream_t stream() const { return stream_; }
     int device() const { return device_; }
     float* weights() const { return d_weights_; }
+    Precision precision() const { return precision_; }
+    // fp16 mode keeps a half mirror of the fp32 weight blob; call after the blob was rewritten in place (RCCL broadcast).
+    void RefreshHalfWeights();
     size_t weight_bytes() const { return weight_floats_ * sizeof(float); }
     size_t device_bytes() const { return device_bytes_; }
     std::mutex& mutex() { return mu_; }
@@ -112,6 +115,8 @@ private:
     int device_ = 0;
     hipStream_t stream_ = nullptr;
     float* d_weights_ = nullptr;
+    void* d_weights16_ = nullptr;      // fp16 mode: the same blob as halfs, same element offsets
+    Precision precision_ = Precision::F32;
     size_t weight_floats_ = 0;
     size_t device_bytes_ = 0;
     bool use_graph_ = true;

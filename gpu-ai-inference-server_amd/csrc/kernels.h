@@ -9,15 +9,19 @@
 namespace ie {
 
 // Strided activation operand: element (n, y, x, c) lives at  base + n*sn + y*sh + x*sw + c*sc.
+// f16 != 0: the buffer holds IEEE half elements (fp16 precision mode); `p` is then only a typed alias of the address and
+// all strides stay in ELEMENTS.
 struct TensorArg {
     float* p = nullptr;
     int n = 0, h = 0, w = 0, c = 0;
     int64_t sn = 0, sh = 0, sw = 0, sc = 0;
+    int f16 = 0;
 };
 
 struct ConvArgs {
     TensorArg in, out;                 // out is always NHWC (sc == 1)
     const float* w = nullptr;          // [Cout][kh][kw][Cin]
+    const void* w16 = nullptr;         // the same weights as halfs at the same element offset (fp16 precision mode)
     const float* bias = nullptr;       // [Cout] or null
     const float* pre_scale = nullptr;  // [Cin] or null: x <- x*scale + shift (then ReLU if pre_relu) before the conv
     const float* pre_shift = nullptr;
@@ -56,6 +60,13 @@ bool ConvRasterEligible(const ConvArgs& a, int tile);
 int ConvRasterTileBn(int tile);
 hipError_t LaunchConvRaster3x3(const ConvArgs& a, int tile, int splitk, hipStream_t stream);
 hipError_t LaunchConvNaive(const ConvArgs& a, hipStream_t stream);
+// fp16 precision mode (kernels_f16.hip): NHWC half activations + half weights on v_mfma_f32_32x32x16_f16, fp32 accumulate,
+// fp32 scale/shift/bias; output half or float.  Same tile table as the fp32 igemm (entries with deep == 0).
+// second pass of a two-pass split-K conv: out = act(sum of a.workspace slabs + bias)
+hipError_t LaunchSplitKReduce(const ConvArgs& a, int splitk, hipStream_t stream);
+hipError_t LaunchConvIgemmF16(const ConvArgs& a, int tile, int splitk, hipStream_t stream);
+hipError_t InitKernelsF16();
+hipError_t LaunchConvertF32ToF16(const float* src, void* dst, int64_t n, hipStream_t stream);
 hipError_t LaunchPool(const PoolArgs& a, hipStream_t stream);
 // out[n, c] = mean over (y, x) of f(in[n, y, x, c]),  f = optional scale/shift/ReLU prologue
 hipError_t LaunchGlobalAvgPool(const TensorArg& in, const TensorArg& out, const float* pre_scale, const float* pre_shift,

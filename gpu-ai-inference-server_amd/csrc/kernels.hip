@@ -33,6 +33,15 @@ namespace ie {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// element access that honours TensorArg::f16 (scalar kernels; the MFMA kernels have dedicated half paths)
+__device__ __forceinline__ float ld_elem(const float* p, int f16, int64_t i) {
+    return f16 ? float(reinterpret_cast<const _Float16*>(p)[i]) : p[i];
+}
+__device__ __forceinline__ void st_elem(float* p, int f16, int64_t i, float v) {
+    if (f16) reinterpret_cast<_Float16*>(p)[i] = _Float16(v);
+    else p[i] = v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // In-launch split-K combine ("the last arriver reduces").  Every K-slice workgroup of an output tile stores its raw
 // accumulators to a slab, publishes them with ONE agent-scope release, and draws a ticket from the tile's counter; the
@@ -202,7 +211,23 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_igemm_kernel(const Con
                 }
         }
         const bool full = (m0 + BM <= M) && (n0 + BN <= Cout);     // workgroup-uniform: interior tiles skip the guards
-        if (full) {
+        if (!partial && a.out.f16) {
+            // fp16 precision mode: this fp32-compute kernel (the stem) feeds half activations
+            _Float16* oh = reinterpret_cast<_Float16*>(a.out.p);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + (wn_i * TN + j) * 32 + r;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int mb = m0 + (wm_i * TM + i) * 32 + 4 * hh;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int m = mb + (e & 3) + 8 * (e >> 2);
+                        if (n < Cout && m < M) oh[int64_t(m) * opitch + n] = _Float16(acc[i][j][e]);
+                    }
+                }
+            }
+        } else if (full) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int n = n0 + (wn_i * TN + j) * 32 + r;
@@ -510,7 +535,8 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_igemm_kernel(const Con
 
 // Sum the split-K slabs, add bias, apply ReLU, write the NHWC view.  One thread per output element (n fastest).
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, const int nsplit, const int64_t M, const int Cout,
-                                     const float* __restrict__ bias, const int relu, float* __restrict__ out, const int64_t opitch) {
+                                     const float* __restrict__ bias, const int relu, float* __restrict__ out, const int64_t opitch,
+                                     const int out_f16) {
     const int64_t idx = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     const int64_t total = M * Cout;
     if (idx >= total) return;
@@ -519,7 +545,15 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, const int nsp
     float v = bias ? bias[n] : 0.f;
     for (int s = 0; s < nsplit; ++s) v += ws[int64_t(s) * total + idx];
     if (relu) v = fmaxf(v, 0.f);
-    out[m * opitch + n] = v;
+    st_elem(out, out_f16, m * opitch + n, v);
+}
+
+hipError_t LaunchSplitKReduce(const ConvArgs& a, int splitk, hipStream_t stream) {
+    const int64_t M = int64_t(a.out.n) * a.out.h * a.out.w;
+    const int64_t total = M * a.out.c;
+    splitk_reduce_kernel<<<dim3(unsigned((total + 255) / 256)), dim3(256), 0, stream>>>(a.workspace, splitk, M, a.out.c, a.bias,
+                                                                                      a.relu, a.out.p, a.out.sw, a.out.f16);
+    return hipGetLastError();
 }
 
 // Resident workgroups the chip can hold for this kernel (occupancy API x CU count), and the persistent grid derived from
@@ -588,7 +622,7 @@ static hipError_t launch_igemm_t(const ConvArgs& a, int splitk, hipStream_t stre
     if (e != hipSuccess || splitk == 1 || a.counters != nullptr) return e;
     const int64_t total = M * a.out.c;
     splitk_reduce_kernel<<<dim3(unsigned((total + 255) / 256)), dim3(256), 0, stream>>>(a.workspace, splitk, M, a.out.c, a.bias,
-                                                                                      a.relu, a.out.p, a.out.sw);
+                                                                                      a.relu, a.out.p, a.out.sw, a.out.f16);
     return hipGetLastError();
 }
 
@@ -601,6 +635,7 @@ static hipError_t init_igemm_t() {
 
 hipError_t LaunchConvIgemm(const ConvArgs& a_in, int tile, int vec, int splitk, hipStream_t stream) {
     ConvArgs a = a_in;
+    if (a.in.f16) return hipErrorInvalidValue;      // half inputs go through LaunchConvIgemmF16
     static const int dbg = [] { const char* e = std::getenv("IE_DEBUG_ABLATE"); return e ? std::atoi(e) : 0; }();
     a.debug = dbg;   // timing-only ablations (wrong results): 1 no loads, 2 no MFMA, 4 no LDS stores, 8 no barrier
     if (a.out.sc != 1) return hipErrorInvalidValue;
@@ -944,7 +979,7 @@ static hipError_t launch_raster_t(const ConvArgs& a, int splitk, hipStream_t str
     if (e != hipSuccess || splitk == 1 || a.counters != nullptr) return e;
     const int64_t M = int64_t(a.out.n) * a.out.h * a.out.w, total = M * a.out.c;
     splitk_reduce_kernel<<<dim3(unsigned((total + 255) / 256)), dim3(256), 0, stream>>>(a.workspace, splitk, M, a.out.c, a.bias,
-                                                                                      a.relu, a.out.p, a.out.sw);
+                                                                                      a.relu, a.out.p, a.out.sw, a.out.f16);
     return hipGetLastError();
 }
 
@@ -953,7 +988,7 @@ int ConvRasterTileBn(int tile) { return (tile >= 0 && tile < kNumRasterTiles) ? 
 bool ConvRasterEligible(const ConvArgs& a, int tile) {
     if (tile < 0 || tile >= kNumRasterTiles) return false;
     if (a.kh != 3 || a.kw != 3 || a.sh != 1 || a.sw != 1 || a.pt != 1 || a.pl != 1) return false;
-    if (a.out.h != a.in.h || a.out.w != a.in.w || a.pre_scale != nullptr) return false;
+    if (a.out.h != a.in.h || a.out.w != a.in.w || a.pre_scale != nullptr || a.in.f16 || a.out.f16) return false;
     if (a.in.sc != 1 || a.out.sc != 1 || (a.in.c & 3) || (a.in.sw & 3) || (reinterpret_cast<uintptr_t>(a.in.p) & 15) ||
         (reinterpret_cast<uintptr_t>(a.w) & 15))
         return false;
@@ -1019,10 +1054,10 @@ __global__ void conv_naive_kernel(const ConvArgs a, const int64_t total) {
         for (int kx = 0; kx < a.kw; ++kx) {
             const int ix = ox * a.sw - a.pl + kx;
             if (unsigned(ix) >= unsigned(a.in.w)) continue;
-            const float* px = a.in.p + int64_t(b) * a.in.sn + int64_t(iy) * a.in.sh + int64_t(ix) * a.in.sw;
+            const int64_t px = int64_t(b) * a.in.sn + int64_t(iy) * a.in.sh + int64_t(ix) * a.in.sw;
             const float* wp = wrow + (ky * a.kw + kx) * Cin;
             for (int c = 0; c < Cin; ++c) {
-                float v = px[int64_t(c) * a.in.sc];
+                float v = ld_elem(a.in.p, a.in.f16, px + int64_t(c) * a.in.sc);
                 if (a.pre_scale) { v = v * a.pre_scale[c] + a.pre_shift[c]; if (a.pre_relu) v = fmaxf(v, 0.f); }
                 acc = fmaf(v, wp[c], acc);
             }
@@ -1030,7 +1065,7 @@ __global__ void conv_naive_kernel(const ConvArgs a, const int64_t total) {
     }
     if (a.bias) acc += a.bias[n];
     if (a.relu) acc = fmaxf(acc, 0.f);
-    a.out.p[int64_t(b) * a.out.sn + int64_t(oy) * a.out.sh + int64_t(ox) * a.out.sw + n] = acc;
+    st_elem(a.out.p, a.out.f16, int64_t(b) * a.out.sn + int64_t(oy) * a.out.sh + int64_t(ox) * a.out.sw + n, acc);
 }
 
 hipError_t LaunchConvNaive(const ConvArgs& a, hipStream_t stream) {
@@ -1045,10 +1080,11 @@ hipError_t LaunchConvNaive(const ConvArgs& a, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------------
 // pooling (NHWC).  V = channels per thread (4 -> 16 B/lane).
 // ------------------------------------------------------------------------------------------------
-template <int V>
+template <int V>      // V = 4: float4 lanes (fp32), V = 8: 8 halfs per lane (fp16), V = 1: scalar, either element type
 __global__ void pool_kernel(const PoolArgs a, const int64_t total) {
     const int64_t idx = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (idx >= total) return;
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     const int CV = a.out.c / V;
     const int c = int(idx % CV) * V;
     int64_t m = idx / CV;
@@ -1068,38 +1104,52 @@ __global__ void pool_kernel(const PoolArgs a, const int64_t total) {
             const bool inside = unsigned(iy) < unsigned(a.in.h) && unsigned(ix) < unsigned(a.in.w);
             if (inside || a.count_include_pad) ++cnt;
             if (!inside) continue;
-            const float* p = a.in.p + int64_t(b) * a.in.sn + int64_t(iy) * a.in.sh + int64_t(ix) * a.in.sw + c;
+            const int64_t off = int64_t(b) * a.in.sn + int64_t(iy) * a.in.sh + int64_t(ix) * a.in.sw + c;
             float x[V];
             if constexpr (V == 4) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+                const f32x4 t = *reinterpret_cast<const f32x4*>(a.in.p + off);
                 x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
-            } else x[0] = p[0];
+            } else if constexpr (V == 8) {
+                const h8 t = *reinterpret_cast<const h8*>(reinterpret_cast<const _Float16*>(a.in.p) + off);
+#pragma unroll
+                for (int v = 0; v < 8; ++v) x[v] = float(t[v]);
+            } else x[0] = ld_elem(a.in.p, a.in.f16, off);
 #pragma unroll
             for (int v = 0; v < V; ++v) acc[v] = a.is_max ? fmaxf(acc[v], x[v]) : acc[v] + x[v];
         }
     }
-    float* o = a.out.p + int64_t(b) * a.out.sn + int64_t(oy) * a.out.sh + int64_t(ox) * a.out.sw + c;
+    const int64_t ooff = int64_t(b) * a.out.sn + int64_t(oy) * a.out.sh + int64_t(ox) * a.out.sw + c;
     const float inv = (!a.is_max && cnt > 0) ? 1.f / float(cnt) : 1.f;
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = a.is_max ? acc[v] : acc[v] * inv;
     if constexpr (V == 4) {
         f32x4 t;
-        t.x = a.is_max ? acc[0] : acc[0] * inv; t.y = a.is_max ? acc[1] : acc[1] * inv;
-        t.z = a.is_max ? acc[2] : acc[2] * inv; t.w = a.is_max ? acc[3] : acc[3] * inv;
-        *reinterpret_cast<f32x4*>(o) = t;
-    } else o[0] = a.is_max ? acc[0] : acc[0] * inv;
+        t.x = acc[0]; t.y = acc[1]; t.z = acc[2]; t.w = acc[3];
+        *reinterpret_cast<f32x4*>(a.out.p + ooff) = t;
+    } else if constexpr (V == 8) {
+        h8 t;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) t[v] = _Float16(acc[v]);
+        *reinterpret_cast<h8*>(reinterpret_cast<_Float16*>(a.out.p) + ooff) = t;
+    } else st_elem(a.out.p, a.out.f16, ooff, acc[0]);
 }
 
 static bool aligned4(const TensorArg& t) {
-    return t.sc == 1 && !(t.c & 3) && !(t.sw & 3) && !(t.sh & 3) && !(t.sn & 3) && !(reinterpret_cast<uintptr_t>(t.p) & 15);
+    return !t.f16 && t.sc == 1 && !(t.c & 3) && !(t.sw & 3) && !(t.sh & 3) && !(t.sn & 3) && !(reinterpret_cast<uintptr_t>(t.p) & 15);
+}
+static bool aligned8h(const TensorArg& t) {
+    return t.f16 && t.sc == 1 && !(t.c & 7) && !(t.sw & 7) && !(t.sh & 7) && !(t.sn & 7) && !(reinterpret_cast<uintptr_t>(t.p) & 15);
 }
 
 hipError_t LaunchPool(const PoolArgs& a, hipStream_t stream) {
     if (a.in.sc != 1 || a.out.sc != 1) return hipErrorInvalidValue;
-    const bool v4 = aligned4(a.in) && aligned4(a.out);
-    const int64_t total = int64_t(a.out.n) * a.out.h * a.out.w * (a.out.c / (v4 ? 4 : 1));
+    const bool v4 = aligned4(a.in) && aligned4(a.out), v8 = aligned8h(a.in) && aligned8h(a.out);
+    const int64_t total = int64_t(a.out.n) * a.out.h * a.out.w * (a.out.c / (v8 ? 8 : (v4 ? 4 : 1)));
     if (total == 0) return hipSuccess;
     const int64_t blocks = (total + 255) / 256;
     if (blocks >= (int64_t(1) << 31)) return hipErrorInvalidValue;
-    if (v4) hipLaunchKernelGGL(pool_kernel<4>, dim3(unsigned(blocks)), dim3(256), 0, stream, a, total);
+    if (v8) hipLaunchKernelGGL(pool_kernel<8>, dim3(unsigned(blocks)), dim3(256), 0, stream, a, total);
+    else if (v4) hipLaunchKernelGGL(pool_kernel<4>, dim3(unsigned(blocks)), dim3(256), 0, stream, a, total);
     else hipLaunchKernelGGL(pool_kernel<1>, dim3(unsigned(blocks)), dim3(256), 0, stream, a, total);
     return hipGetLastError();
 }
@@ -1121,7 +1171,7 @@ __global__ __launch_bounds__(256) void gap_kernel(const TensorArg in, const Tens
     if (cok)
         for (int p = g; p < HW; p += 4) {
             const int y = p / in.w, x = p - y * in.w;
-            float v = in.p[int64_t(b) * in.sn + int64_t(y) * in.sh + int64_t(x) * in.sw + c];
+            float v = ld_elem(in.p, in.f16, int64_t(b) * in.sn + int64_t(y) * in.sh + int64_t(x) * in.sw + c);
             if (ps) { v = v * s + t; }
             if (pre_relu) v = fmaxf(v, 0.f);
             acc += v;
@@ -1130,7 +1180,7 @@ __global__ __launch_bounds__(256) void gap_kernel(const TensorArg in, const Tens
     __syncthreads();
     if (g == 0 && cok) {
         const float tot = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
-        out.p[int64_t(b) * out.sn + c] = tot / float(HW);
+        st_elem(out.p, out.f16, int64_t(b) * out.sn + c, tot / float(HW));
     }
 }
 
@@ -1153,11 +1203,11 @@ __global__ void eltwise_kernel(const EltArgs a, const int64_t total) {
     const int x = int(m % a.out.w); m /= a.out.w;
     const int y = int(m % a.out.h);
     const int b = int(m / a.out.h);
-    float v = a.a.p[int64_t(b) * a.a.sn + int64_t(y) * a.a.sh + int64_t(x) * a.a.sw + int64_t(c) * a.a.sc];
+    float v = ld_elem(a.a.p, a.a.f16, int64_t(b) * a.a.sn + int64_t(y) * a.a.sh + int64_t(x) * a.a.sw + int64_t(c) * a.a.sc);
     if (a.scale) v = v * a.scale[c] + a.shift[c];
-    if (a.b.p) v += a.b.p[int64_t(b) * a.b.sn + int64_t(y) * a.b.sh + int64_t(x) * a.b.sw + int64_t(c) * a.b.sc];
+    if (a.b.p) v += ld_elem(a.b.p, a.b.f16, int64_t(b) * a.b.sn + int64_t(y) * a.b.sh + int64_t(x) * a.b.sw + int64_t(c) * a.b.sc);
     if (a.relu) v = fmaxf(v, 0.f);
-    a.out.p[int64_t(b) * a.out.sn + int64_t(y) * a.out.sh + int64_t(x) * a.out.sw + int64_t(c) * a.out.sc] = v;
+    st_elem(a.out.p, a.out.f16, int64_t(b) * a.out.sn + int64_t(y) * a.out.sh + int64_t(x) * a.out.sw + int64_t(c) * a.out.sc, v);
 }
 
 hipError_t LaunchEltwise(const EltArgs& a, hipStream_t stream) {
@@ -1187,8 +1237,8 @@ __global__ void copy_kernel(const TensorArg in, const TensorArg out, const int o
         y = int(m % out.h); m /= out.h;
         c = int(m % out.c); b = int(m / out.c);
     }
-    out.p[int64_t(b) * out.sn + int64_t(y) * out.sh + int64_t(x) * out.sw + int64_t(c) * out.sc] =
-        in.p[int64_t(b) * in.sn + int64_t(y) * in.sh + int64_t(x) * in.sw + int64_t(c) * in.sc];
+    st_elem(out.p, out.f16, int64_t(b) * out.sn + int64_t(y) * out.sh + int64_t(x) * out.sw + int64_t(c) * out.sc,
+            ld_elem(in.p, in.f16, int64_t(b) * in.sn + int64_t(y) * in.sh + int64_t(x) * in.sw + int64_t(c) * in.sc));
 }
 
 hipError_t LaunchCopy(const TensorArg& in, const TensorArg& out, hipStream_t stream) {

@@ -190,9 +190,10 @@ ModelInfo DescribeModel(const OnnxModel& m) {
     return info;
 }
 
-Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& input_shapes) {
+Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& input_shapes, Precision precision) {
     Lowering L(m);
     Plan plan;
+    plan.precision = precision;
     if (input_shapes.size() != m.inputs.size())
         fail("Expected " + std::to_string(m.inputs.size()) + " inputs, got " + std::to_string(input_shapes.size()));
 
@@ -634,11 +635,22 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                 free_pool.insert({plan.buffer_floats[size_t(L.vals[v].buf)], L.vals[v].buf});
     }
 
+    // fp16 mode: every buffer except the graph's own inputs/outputs (dedicated, never recycled) holds halfs
+    auto mark_buffer_types = [&] {
+        plan.buffer_f16.assign(plan.buffer_floats.size(), precision == Precision::F16 ? 1 : 0);
+        for (size_t v = 0; v < L.vals.size(); ++v)
+            if (L.vals[v].is_input && L.vals[L.vals[v].root].buf >= 0) plan.buffer_f16[size_t(L.vals[L.vals[v].root].buf)] = 0;
+        for (int v : out_vals)
+            if (L.vals[L.vals[v].root].buf >= 0) plan.buffer_f16[size_t(L.vals[L.vals[v].root].buf)] = 0;
+    };
+    mark_buffer_types();
+
     auto view_of = [&](int v) {
         const Val& X = L.vals[v];
         const Val& R = L.vals[X.root];
         View w;
         w.buf = R.buf;
+        w.f16 = R.buf >= 0 && plan.buffer_f16[size_t(R.buf)] != 0;
         w.n = X.n; w.c = X.c; w.h = X.h; w.w = X.w;
         w.c_off = X.abs_off;
         w.pitch = R.c;
@@ -649,11 +661,12 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
 
     // ---- emit steps --------------------------------------------------------------------------------
     auto push_vec = [&](const std::vector<float>& v) {
-        while (plan.weights.size() % 4) plan.weights.push_back(0.f);
+        while (plan.weights.size() % 8) plan.weights.push_back(0.f);   // 32 B in the fp32 blob, 16 B in its half mirror
         int64_t off = int64_t(plan.weights.size());
         plan.weights.insert(plan.weights.end(), v.begin(), v.end());
         return off;
     };
+    auto vbytes = [](const View& v) { return double(v.numel()) * (v.f16 ? 2.0 : 4.0); };
     for (int idx : order) {
         const LNode& n = L.nodes[idx];
         if (n.kind == L_ALIAS) continue;
@@ -673,7 +686,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                     c.out = view_of(n.out);
                     c.out.c = src.c;
                     c.out.c_off += off;
-                    c.bytes = 8.0 * double(c.in.numel());
+                    c.bytes = vbytes(c.in) + vbytes(c.out);
                     plan.steps.push_back(c);
                 }
                 off += src.c;
@@ -696,26 +709,29 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                 if (!n.bias.empty()) s.bias_off = push_vec(n.bias);
                 int64_t M = s.out.n * s.out.h * s.out.w, N = s.out.c, K = int64_t(n.kh) * n.kw * s.in.c;
                 s.flops = 2.0 * double(M) * double(N) * double(K);
-                s.bytes = 4.0 * (double(s.in.numel()) + double(s.out.numel()) + double(n.w.size()));
-                bool vec_ok = !s.in.nchw && s.in.c % 4 == 0 && s.in.pitch % 4 == 0 && s.in.c_off % 4 == 0 && n.kh * n.kw <= 32 &&
+                const bool in16 = s.in.f16;
+                s.bytes = vbytes(s.in) + vbytes(s.out) + (in16 ? 2.0 : 4.0) * double(n.w.size());
+                bool vec_ok = !in16 && !s.in.nchw && s.in.c % 4 == 0 && s.in.pitch % 4 == 0 && s.in.c_off % 4 == 0 && n.kh * n.kw <= 32 &&
                               s.in.n * s.in.h * s.in.w * s.in.pitch * 4 < (int64_t(1) << 31) && int64_t(n.w.size()) * 4 < (int64_t(1) << 31);
+                // fp16 MFMA path: 16-byte chunks of 8 halfs, so channel counts / slice offsets must be multiples of 8
+                const bool vec16_ok = in16 && !s.in.nchw && s.in.c % 8 == 0 && s.in.pitch % 8 == 0 && s.in.c_off % 8 == 0 && n.kh * n.kw <= 32 &&
+                                      s.in.n * s.in.h * s.in.w * s.in.pitch * 2 < (int64_t(1) << 31) && int64_t(n.w.size()) * 2 < (int64_t(1) << 31) &&
+                                      s.out.n * s.out.h * s.out.w * s.out.pitch < (int64_t(1) << 31);
+                const int64_t bk = in16 ? 2 * kIgemmBK : kIgemmBK;       // K-tile depth in elements (128 B per LDS row either way)
                 if (M * N < 2048 && K <= 4096) s.algo = ConvAlgo::Naive;
-                else if (vec_ok) s.algo = ConvAlgo::IgemmVec;
-                else if (K <= 2048) s.algo = ConvAlgo::IgemmScalar;
+                else if (vec_ok || vec16_ok) s.algo = ConvAlgo::IgemmVec;
+                else if (K <= 2048 && !in16) s.algo = ConvAlgo::IgemmScalar;
                 else s.algo = ConvAlgo::Naive;
                 s.tile = choose_tile(M, N);
                 s.splitk = 1;
                 const int heuristic_tile = s.tile;
                 // Test / tuning overrides (read at plan time): IE_FORCE_TILE=<0..6>, IE_FORCE_ALGO=naive|scalar
-                if (const char* ft = std::getenv("IE_FORCE_TILE")) {
-                    int t = std::atoi(ft);
-                    if (t >= 0 && t < kNumIgemmTiles && (t < kNumIgemmBaseTiles || s.algo == ConvAlgo::IgemmVec)) s.tile = t;
-                }
                 if (const char* fa = std::getenv("IE_FORCE_ALGO")) {
                     std::string f = fa;
                     if (f == "naive") s.algo = ConvAlgo::Naive;
-                    else if (f == "scalar" && K <= 2048) s.algo = ConvAlgo::IgemmScalar;
-                    else if (f == "igemm" && s.algo == ConvAlgo::Naive) s.algo = vec_ok ? ConvAlgo::IgemmVec : (K <= 2048 ? ConvAlgo::IgemmScalar : ConvAlgo::Naive);
+                    else if (f == "scalar" && K <= 2048 && !in16) s.algo = ConvAlgo::IgemmScalar;
+                    else if (f == "igemm" && s.algo == ConvAlgo::Naive)
+                        s.algo = (vec_ok || vec16_ok) ? ConvAlgo::IgemmVec : (K <= 2048 && !in16 ? ConvAlgo::IgemmScalar : ConvAlgo::Naive);
                     else if (f == "raster") {
                         const bool eligible = vec_ok && n.kh == 3 && n.kw == 3 && n.sh == 1 && n.sw == 1 && n.pt == 1 && n.pl == 1 &&
                                               n.pb == 1 && n.pr == 1 && !n.has_pre;
@@ -723,8 +739,13 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                             s.algo = ConvAlgo::Raster3x3;
                             s.tile = 0;
                             if (const char* ft = std::getenv("IE_FORCE_TILE")) { int t = std::atoi(ft); if (t >= 0 && t < 6) s.tile = t; }
-                        } else if (s.algo == ConvAlgo::Naive) s.algo = vec_ok ? ConvAlgo::IgemmVec : (K <= 2048 ? ConvAlgo::IgemmScalar : ConvAlgo::Naive);
+                        } else if (s.algo == ConvAlgo::Naive)
+                            s.algo = (vec_ok || vec16_ok) ? ConvAlgo::IgemmVec : (K <= 2048 && !in16 ? ConvAlgo::IgemmScalar : ConvAlgo::Naive);
                     }
+                }
+                if (const char* ft = s.algo == ConvAlgo::Raster3x3 ? nullptr : std::getenv("IE_FORCE_TILE")) {
+                    int t = std::atoi(ft);
+                    if (t >= 0 && t < kNumIgemmTiles && (t < kNumIgemmBaseTiles || s.algo == ConvAlgo::IgemmVec) && !(in16 && kIgemmTiles[t].deep)) s.tile = t;
                 }
                 if (s.algo != ConvAlgo::IgemmVec && s.algo != ConvAlgo::Raster3x3 && s.tile >= kNumIgemmBaseTiles)
                     s.tile = heuristic_tile;       // K-group tiles exist for the vector path only
@@ -739,7 +760,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                     // per split.  (Deterministic two-pass reduction, see kernels.hip.)
                     const IgemmTile& T = kIgemmTiles[s.tile];
                     const int64_t wgs = ((M + T.bm - 1) / T.bm) * ((N + T.bn - 1) / T.bn);
-                    const int64_t cblocks = (s.in.c + kIgemmBK - 1) / kIgemmBK;
+                    const int64_t cblocks = (s.in.c + bk - 1) / bk;
                     const int64_t KT = s.algo == ConvAlgo::IgemmVec ? int64_t(n.kh) * n.kw * cblocks : (K + kIgemmBK - 1) / kIgemmBK;
                     if (wgs < 384 && KT >= 4) {
                         int64_t want = (768 + wgs - 1) / wgs;
@@ -758,36 +779,36 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                 s.pool_max = n.kind == L_MAXPOOL;
                 s.count_include_pad = n.count_include_pad;
                 s.kh = n.kh; s.kw = n.kw; s.sh = n.sh; s.sw = n.sw; s.pt = n.pt; s.pl = n.pl; s.pb = n.pb; s.pr = n.pr;
-                s.bytes = 4.0 * (double(s.in.numel()) + double(s.out.numel()));
+                s.bytes = vbytes(s.in) + vbytes(s.out);
                 s.flops = double(s.out.numel()) * n.kh * n.kw;
                 break;
             case L_GAP:
                 s.kind = StepKind::GlobalAvgPool;
-                s.bytes = 4.0 * (double(s.in.numel()) + double(s.out.numel()));
+                s.bytes = vbytes(s.in) + vbytes(s.out);
                 s.flops = double(s.in.numel());
                 break;
             case L_AFFINE:
                 s.kind = StepKind::Eltwise;
                 s.pre_scale_off = push_vec(n.s);
                 s.pre_shift_off = push_vec(n.t);
-                s.bytes = 8.0 * double(s.in.numel());
+                s.bytes = vbytes(s.in) + vbytes(s.out);
                 s.flops = 2.0 * double(s.in.numel());
                 break;
             case L_RELU:
                 s.kind = StepKind::Eltwise;
                 s.relu = true;
-                s.bytes = 8.0 * double(s.in.numel());
+                s.bytes = vbytes(s.in) + vbytes(s.out);
                 break;
             case L_ADD:
                 s.kind = StepKind::Eltwise;
                 s.in2 = view_of(n.in[1]);
                 s.has_in2 = true;
-                s.bytes = 12.0 * double(s.in.numel());
+                s.bytes = vbytes(s.in) + vbytes(s.in2) + vbytes(s.out);
                 s.flops = double(s.in.numel());
                 break;
             case L_COPY:
                 s.kind = StepKind::Copy;
-                s.bytes = 8.0 * double(s.in.numel());
+                s.bytes = vbytes(s.in) + vbytes(s.out);
                 break;
             default: fail("internal planner error: unexpected node kind");
         }
@@ -797,7 +818,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
         plan.total_bytes += s.bytes;
         plan.steps.push_back(std::move(s));
     }
-    while (plan.weights.size() % 4) plan.weights.push_back(0.f);
+    while (plan.weights.size() % 8) plan.weights.push_back(0.f);
 
     // ---- I/O descriptors ---------------------------------------------------------------------------
     for (size_t i = 0; i < m.inputs.size(); ++i) {
@@ -809,6 +830,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
         int v = L.get_val(d.name);
         if (!used[size_t(L.vals[v].root)]) {   // input never consumed: still give it a staging buffer
             plan.buffer_floats.push_back(root_floats(v));
+            plan.buffer_f16.push_back(0);
             L.vals[v].buf = int(plan.buffer_floats.size()) - 1;
         }
         d.view = view_of(v);
@@ -830,7 +852,8 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
 
 static void json_view(std::ostringstream& o, const View& v) {
     o << "{\"buf\":" << v.buf << ",\"n\":" << v.n << ",\"c\":" << v.c << ",\"h\":" << v.h << ",\"w\":" << v.w
-      << ",\"c_off\":" << v.c_off << ",\"pitch\":" << v.pitch << ",\"nchw\":" << (v.nchw ? "true" : "false") << "}";
+      << ",\"c_off\":" << v.c_off << ",\"pitch\":" << v.pitch << ",\"nchw\":" << (v.nchw ? "true" : "false")
+      << ",\"f16\":" << (v.f16 ? "true" : "false") << "}";
 }
 static std::string json_escape(const std::string& s) {
     std::string o;
@@ -857,7 +880,8 @@ std::string PlanToJson(const Plan& p) {
     }
     o << "],\"buffers\":[";
     for (size_t i = 0; i < p.buffer_floats.size(); ++i) o << (i ? "," : "") << p.buffer_floats[i];
-    o << "],\"workspace_floats\":" << p.workspace_floats << ",\"weight_floats\":" << p.weights.size() << ",\"total_flops\":" << p.total_flops
+    o << "],\"precision\":\"" << (p.precision == Precision::F16 ? "fp16" : "fp32") << "\",\"activation_bytes\":" << p.activation_bytes()
+      << ",\"workspace_floats\":" << p.workspace_floats << ",\"weight_floats\":" << p.weights.size() << ",\"total_flops\":" << p.total_flops
       << ",\"total_bytes\":" << p.total_bytes << ",\"steps\":[";
     for (size_t i = 0; i < p.steps.size(); ++i) {
         const Step& s = p.steps[i];

@@ -24,8 +24,14 @@ struct View {
     int64_t c_off = 0;    // first channel inside the buffer's pixel row
     int64_t pitch = 0;    // floats per pixel row of the buffer (>= c_off + c)
     bool nchw = false;    // dense NCHW (pitch/c_off unused)
+    bool f16 = false;     // elements are IEEE halfs (fp16 precision mode: every buffer that is not a graph input/output)
     int64_t numel() const { return n * c * h * w; }
 };
+
+// Storage/compute precision of a plan.  F16: activations between the graph's fp32 inputs and outputs are stored as halfs and
+// the convolutions run on the fp16 MFMA path with fp32 accumulation (BASELINE.json configs[2-3]); folded BN scale/shift,
+// biases and split-K partial sums stay fp32.
+enum class Precision : int { F32 = 0, F16 = 1 };
 
 enum class StepKind : int { Conv = 0, Pool = 1, GlobalAvgPool = 2, Eltwise = 3, Copy = 4 };
 
@@ -69,12 +75,19 @@ struct IoDesc {
 
 struct Plan {
     std::vector<IoDesc> inputs, outputs;
-    std::vector<int64_t> buffer_floats;   // size of each device activation buffer
+    Precision precision = Precision::F32;
+    std::vector<int64_t> buffer_floats;   // size of each device activation buffer in ELEMENTS
+    std::vector<char> buffer_f16;         // element type of each buffer (1 = half)
     std::vector<Step> steps;
     std::vector<float> weights;           // packed blob (batch independent)
     int64_t workspace_floats = 0;         // split-K partial-sum slabs (max over steps of splitk*M*Cout)
     double total_flops = 0, total_bytes = 0;
     int64_t activation_floats() const { int64_t s = 0; for (auto b : buffer_floats) s += b; return s; }
+    int64_t activation_bytes() const {
+        int64_t s = 0;
+        for (size_t i = 0; i < buffer_floats.size(); ++i) s += buffer_floats[i] * (buffer_f16[i] ? 2 : 4);
+        return s;
+    }
 };
 
 // Static (shape independent) facts, available right after parsing: what ExtractModelMetadata
@@ -87,7 +100,7 @@ ModelInfo DescribeModel(const OnnxModel& m);
 
 // Build the plan for concrete input shapes (one entry per graph input, in graph order).
 // Throws std::runtime_error with an ORT-like message on unsupported ops or shape mismatches.
-Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& input_shapes);
+Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& input_shapes, Precision precision = Precision::F32);
 
 std::string PlanToJson(const Plan& p);
 

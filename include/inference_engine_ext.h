@@ -34,6 +34,11 @@ void* EngineGetStream(ModelHandle handle);
 char* EngineProfile(ModelHandle handle, int iters, ErrorMessage* error);
 /* Packed fp32 weight blob in HBM (folded BN scale/shift, repacked conv weights). */
 bool EngineGetWeightBlob(ModelHandle handle, void** d_ptr, size_t* bytes, ErrorMessage* error);
+/* Tell the engine the fp32 blob was rewritten in place (e.g. by an RCCL broadcast): in fp16 precision mode the half
+ * mirror the MFMA path reads is re-derived from it.  No-op in fp32 mode. */
+bool EngineWeightsUpdated(ModelHandle handle, ErrorMessage* error);
+/* 0 = fp32, 1 = fp16 (IE_PRECISION or config.json "precision"), -1 = model not loaded. */
+int EngineGetPrecision(ModelHandle handle);
 /* Synchronous hipMemcpy on the model's device: kind 1 = host->device, 2 = device->host, 3 = device->device.
  * Lets a test or benchmark fill / read the engine-owned buffers returned by EnginePrepare. */
 bool EngineMemcpy(ModelHandle handle, void* dst, const void* src, size_t bytes, int kind, ErrorMessage* error);

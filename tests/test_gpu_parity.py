@@ -356,14 +356,14 @@ def test_c_replay_harness_on_gpu(model_repo, engine_lib):
     assert "count=1 mem=10485780" in out["CALL ModelGetStats"]
 
 
-def _random_conv_graph(rs, case):
+def _random_conv_graph(rs, case, cin_choices=(3, 4, 8, 12, 20, 32, 36, 64, 96)):
     """One random Conv (+ optional pre-activation BN/ReLU, bias, post BN/ReLU, concat partner) as an ONNX graph."""
     from gpu_ai_inference_server_amd.modelgen import onnx_pb as pb
     n = int(rs.choice([1, 2, 3, 5]))
     k = int(rs.choice([1, 1, 3, 3, 5, 7]))
     stride = int(rs.choice([1, 1, 2]))
     pad = int(rs.choice([0, k // 2]))
-    cin = int(rs.choice([3, 4, 8, 12, 20, 32, 36, 64, 96]))
+    cin = int(rs.choice(list(cin_choices)))
     cout = int(rs.choice([1, 5, 16, 32, 40, 64, 100, 128]))
     h = int(rs.randint(max(k, 3), 24))
     w = int(rs.randint(max(k, 3), 24))
@@ -483,3 +483,177 @@ def test_dynamic_batcher_coalesces_concurrent_requests(densenet_repo):
         assert dims3 == [3, 1000, 1, 1] and rel_err(y3.reshape(3, 1000), ref[2:5]) < 2e-5
     finally:
         m.Destroy()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fp16 precision mode (BASELINE.json configs[2-3]).  The reference never runs fp16 (its ONNX Runtime session computes the
+# model's own fp32), so there is no reference-side number to pin: "parity unpinned".  The checker is the float64 oracle /
+# fixture; the tolerance is this repo's own statement: activations and weights are rounded to half (2^-11 relative per
+# element), every accumulation, BN scale/shift, bias and split-K slab is fp32, so the error is a rounding random walk over
+# the layers.  Bound used: 1e-2 of max|ref| per graph (2e-2 for the 121-layer DenseNet) plus identical top-1 classes.
+# ---------------------------------------------------------------------------------------------------------------------
+F16_RTOL = 1e-2
+
+
+def _f16_env(**extra):
+    env = dict(IE_PRECISION="fp16")
+    env.update(extra)
+    return env
+
+
+def _run_with_env(env, fn):
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k_ in env:
+            os.environ.pop(k_, None)
+
+
+def _f16_densenet_bytes():
+    # every channel count / concat offset a multiple of 8: all dense-layer convs take the fp16 MFMA path
+    return models.densenet(3, growth=16, blocks=(2, 3, 2), stem=32, image=48, classes=24, seed=77)
+
+
+@pytest.mark.parametrize("name", sorted(MINI) + ["f16_densenet"])
+def test_fp16_mode_graphs_vs_float64_oracle(model_repo, tmp_path, name):
+    if name == "f16_densenet":
+        mb, iname, ishape = _f16_densenet_bytes(), "data_0", (3, 3, 48, 48)
+        path = models.write_repo(str(tmp_path), name, mb)
+    else:
+        mk, iname, ishape = MINI[name]
+        mb = mk(models)
+        path = os.path.join(model_repo, name, "1")
+    om = O.load_model(mb)
+    oname, oshape, _ = om.outputs[0]
+    x = models.synthetic_input(ishape, stream=name)
+    ref = O.run(om, {iname: x}, dtype=np.float64)[oname]
+
+    def go():
+        plan = B.DescribeModel(path, ishape[0])["plan"]
+        assert plan["precision"] == "fp16"
+        assert all(not st["in"]["f16"] for st in plan["steps"][:1]) and not plan["outputs"][0]["view"]["f16"]   # graph I/O stays fp32
+        m = B.CreateModel(path, name)
+        try:
+            assert B.Precision(m) == "fp16"
+            y, dims = infer(m, "", iname, x, oname, oshape)
+            y2, _ = infer(m, "", iname, x, oname, oshape)
+        finally:
+            m.Destroy()
+        return plan, y, y2, dims
+    plan, y, y2, dims = _run_with_env(_f16_env(), go)
+    assert dims == list(oshape)
+    np.testing.assert_array_equal(y, y2)
+    e = rel_err(y, ref)
+    n16 = sum(1 for st in plan["steps"] if st["kind"] == "conv" and st["in"]["f16"] and st["algo"] == "igemm_vec")
+    print(f"{name} fp16: rel err vs float64 oracle {e:.2e}; {n16} convs on the fp16 MFMA kernel")
+    assert e < F16_RTOL
+    if name == "f16_densenet":
+        assert n16 >= 8
+
+
+@pytest.mark.parametrize("tile", range(11))
+@pytest.mark.parametrize("splitk", [1, 3])
+def test_fp16_every_tile_and_split_k(tmp_path, tile, splitk):
+    """Each tile configuration of conv_igemm_f16_kernel (base tiles and K-group tiles), with and without the two-pass split-K."""
+    mb = _f16_densenet_bytes()
+    path = models.write_repo(str(tmp_path), "f16t", mb)
+    om = O.load_model(mb)
+    x = models.synthetic_input((3, 3, 48, 48), stream="f16_densenet")
+    ref = O.run(om, {"data_0": x}, dtype=np.float64)["fc6_1"]
+
+    def go():
+        plan = B.DescribeModel(path, 3)["plan"]
+        forced = [st for st in plan["steps"] if st["kind"] == "conv" and st["in"]["f16"] and st["algo"] == "igemm_vec"]
+        assert forced and all(st["tile"] == tile and st["splitk"] == splitk for st in forced)
+        m = B.CreateModel(path, "f16t")
+        try:
+            return infer(m, "", "data_0", x, "fc6_1", [3, 24, 1, 1])[0]
+        finally:
+            m.Destroy()
+    y = _run_with_env(_f16_env(IE_FORCE_ALGO="igemm", IE_FORCE_TILE=str(tile), IE_FORCE_SPLITK=str(splitk)), go)
+    e = rel_err(y, ref)
+    assert e < F16_RTOL, (tile, splitk, e)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_fp16_random_conv_graphs_vs_oracle(tmp_path, seed):
+    """Seeded random convolutions with 8-aligned channels (kernel 1..7, stride 1/2, padding, fused BN+ReLU prologue /
+    epilogue, channel-offset stores into a Concat buffer) on the fp16 path: autotuned, heuristic, forced K-group tile, split-K."""
+    rs = np.random.RandomState(2000 + seed)
+    modes = [dict(), dict(IE_AUTOTUNE="0"), dict(IE_FORCE_ALGO="igemm", IE_FORCE_TILE=str(7 + seed)),
+             dict(IE_FORCE_ALGO="igemm", IE_FORCE_SPLITK="2", IE_FORCE_TILE=str(seed + 3)), dict(IE_FORCE_ALGO="naive")]
+    worst = 0.0
+    for case in range(10):
+        mb, ishape, oshape, desc = _random_conv_graph(rs, case, cin_choices=(8, 16, 24, 40, 64, 72, 96, 136))
+        d = models.write_repo(str(tmp_path), f"h{seed}_{case}", mb)
+        om = O.load_model(mb)
+        x = rs.rand(*ishape).astype(np.float32)
+        ref = O.run(om, {"x": x}, dtype=np.float64)["out"]
+        env = _f16_env(**modes[case % len(modes)])
+
+        def go():
+            m = B.CreateModel(d, "h")
+            try:
+                return infer(m, "", "x", x, "out", oshape)
+            finally:
+                m.Destroy()
+        y, dims = _run_with_env(env, go)
+        assert dims == list(oshape)
+        e = rel_err(y, ref)
+        worst = max(worst, e)
+        assert e < F16_RTOL, (desc, env, e)
+    print(f"fp16 seed {seed}: worst rel err {worst:.2e}")
+
+
+def test_fp16_densenet121_fixture_and_batch_independence(densenet_repo, tmp_path):
+    """DenseNet-121 in fp16 mode selected through config.json ("precision": "fp16"), B=2 against the float64 fixture and the
+    B=32 size-independent property (each image's logits equal that image run alone, up to summation-order rounding)."""
+    import shutil
+    root = str(tmp_path / "repo")
+    shutil.copytree(densenet_repo, root)
+    cfg_path = os.path.join(root, "densenet_onnx", "1", "config.json")
+    with open(cfg_path) as f:
+        cfg = f.read()
+    with open(cfg_path, "w") as f:
+        f.write(cfg[:-1] + ',"precision":"fp16"}')
+    mgr = B.NewInferenceManager(root)
+    try:
+        mgr.LoadModel("densenet_onnx")
+        g = np.load(os.path.join(GOLD, "densenet121_b2.npz"))
+        x = models.synthetic_input((2, 3, 224, 224))
+        y, dims = infer(mgr, "densenet_onnx", "data_0", x, "fc6_1", [2, 1000, 1, 1])
+        assert dims == [2, 1000, 1, 1]
+        e = rel_err(y.reshape(2, 1000), g["logits_f64"])
+        print(f"densenet121 fp16 B=2: rel err vs float64 fixture {e:.2e}")
+        assert e < 2e-2
+        assert np.argmax(y.reshape(2, 1000), 1).tolist() == np.argmax(g["logits_f64"], 1).tolist()
+        x32 = models.synthetic_input((32, 3, 224, 224), stream="b32")
+        y32, _ = infer(mgr, "densenet_onnx", "data_0", x32, "fc6_1", [32, 1000, 1, 1])
+        y32 = y32.reshape(32, 1000)
+        assert np.isfinite(y32).all() and np.abs(y32).max() < 50
+        for i in (0, 17, 31):
+            y1, _ = infer(mgr, "densenet_onnx", "data_0", x32[i:i + 1], "fc6_1", [1, 1000, 1, 1])
+            assert rel_err(y1.reshape(1000), y32[i]) < 5e-3
+    finally:
+        mgr.Shutdown()
+
+
+def test_fp16_test_model_known_answer(model_repo):
+    """The reference's pinned known answer (docs/run_server.ipynb:174-175) still holds to half precision in fp16 mode."""
+    def go():
+        m = B.CreateModel(os.path.join(model_repo, "test_model", "1"), "test_model")
+        try:
+            x = np.array([[-0.01349723, -1.0577109, 0.82254493]], np.float32)
+            return infer(m, "", "input", x, "output", [1, 2])[0]
+        finally:
+            m.Destroy()
+    y = _run_with_env(_f16_env(), go)
+    np.testing.assert_allclose(np.asarray(y).reshape(-1), [-0.6017066, 1.8522782], rtol=5e-3, atol=5e-3)
+
+
+def test_unknown_precision_is_a_load_error(model_repo):
+    def go():
+        with pytest.raises(RuntimeError, match="unsupported precision"):
+            B.CreateModel(os.path.join(model_repo, "test_model", "1"), "test_model")
+    _run_with_env(dict(IE_PRECISION="int3"), go)
