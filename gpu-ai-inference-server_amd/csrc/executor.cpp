@@ -121,6 +121,7 @@ DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id, 
     std::call_once(g_kernels_once, [] {
         g_kernels_err = InitKernels();
         if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsF16();
+        if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsWs();
     });
     check(g_kernels_err, "InitKernels");
     check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
@@ -142,7 +143,8 @@ DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id, 
             std::string tok;
             while (is >> tok && tok != ":") key.push_back(std::stoll(tok));
             int t = -1, sp = 0;
-            if ((is >> t >> sp) && ((t >= 0 && t < kNumIgemmTiles) || (t >= 100 && t < 100 + kNumConvRasterTiles)) && sp >= 1 && sp <= 64)
+            if ((is >> t >> sp) && ((t >= 0 && t < kNumIgemmTiles) || (t >= 100 && t < 100 + kNumConvRasterTiles) || (t >= 200 && t < 200 + kNumConvWsTiles)) &&
+                sp >= 1 && sp <= 64)
                 tune_cache_[key] = {t, sp};
         }
     }
@@ -338,8 +340,9 @@ void DeviceModel::Autotune(PlanInstance& pi) {
                                         s.in.nchw, int64_t(s.algo), s.pre_scale_off >= 0, s.bias_off >= 0};
             if (s.in.f16 || s.out.f16) { key.push_back(s.in.f16); key.push_back(s.out.f16); }   // fp32 signatures keep 17 entries
             auto hit = tune_cache_.find(key);
-            auto apply = [&](int enc_tile, int sp) {     // tile >= 100 encodes the raster kernel
-                if (enc_tile >= 100) { s.algo = ConvAlgo::Raster3x3; s.tile = enc_tile - 100; }
+            auto apply = [&](int enc_tile, int sp) {     // tile >= 100 encodes the raster kernel, >= 200 the weights-stationary 1x1
+                if (enc_tile >= 200) { s.algo = ConvAlgo::Ws1x1; s.tile = enc_tile - 200; }
+                else if (enc_tile >= 100) { s.algo = ConvAlgo::Raster3x3; s.tile = enc_tile - 100; }
                 else s.tile = enc_tile;
                 s.splitk = sp;
             };
@@ -387,6 +390,19 @@ void DeviceModel::Autotune(PlanInstance& pi) {
                     }
                 }
             }
+            // fp16 mode, 1x1/s1: weights-stationary streaming kernel
+            if (s.in.f16 && s.algo == ConvAlgo::IgemmVec && s.kh == 1 && s.kw == 1) {
+                ConvArgs probe = MakeConvArgs(pi, s);
+                for (int t = 0; t < kNumConvWsTiles; ++t) {
+                    if (!ConvWsEligible(probe, t)) continue;
+                    Step trial = s;
+                    trial.algo = ConvAlgo::Ws1x1;
+                    trial.tile = t;
+                    trial.splitk = 1;
+                    float ms = time_trial(trial);
+                    if (ms < best) { best = ms; best_tile = 200 + t; best_split = 1; }
+                }
+            }
             for (int t = 0; t < kNumIgemmTiles; ++t) {
                 const IgemmTile& T = kIgemmTiles[t];
                 if ((T.bn > 32 && N <= 32) || (T.bn > 64 && N <= 64)) continue;
@@ -425,27 +441,39 @@ void DeviceModel::Autotune(PlanInstance& pi) {
     }
 }
 
+ConvArgs DeviceModel::MakeConvArgs(const PlanInstance& pi, const Step& s) const {
+    const float* wb = d_weights_;
+    auto wp = [&](int64_t off) -> const float* { return off >= 0 ? wb + off : nullptr; };
+    ConvArgs a;
+    a.in = make_arg(pi, s.in);
+    a.out = make_arg(pi, s.out);
+    a.w = wp(s.w_off);
+    a.w16 = d_weights16_ && s.w_off >= 0 ? static_cast<const char*>(d_weights16_) + s.w_off * 2 : nullptr;
+    a.bias = wp(s.bias_off);
+    a.pre_scale = wp(s.pre_scale_off);
+    a.pre_shift = wp(s.pre_shift_off);
+    if (d_weights16_ && s.pre_scale_off >= 0) {
+        a.pre_scale16 = static_cast<const char*>(d_weights16_) + s.pre_scale_off * 2;
+        a.pre_shift16 = static_cast<const char*>(d_weights16_) + s.pre_shift_off * 2;
+    }
+    a.kh = s.kh; a.kw = s.kw; a.sh = s.sh; a.sw = s.sw; a.pt = s.pt; a.pl = s.pl;
+    a.pre_relu = s.pre_relu; a.relu = s.relu;
+    a.workspace = pi.workspace;
+    a.workspace_floats = pi.workspace_floats;
+    a.counters = pi.counters;
+    a.num_counters = pi.counters ? kNumCounters : 0;
+    return a;
+}
+
 void DeviceModel::LaunchStep(const PlanInstance& pi, const Step& s, hipStream_t stream_) {
     const float* wb = d_weights_;
     auto wp = [&](int64_t off) -> const float* { return off >= 0 ? wb + off : nullptr; };
     switch (s.kind) {
         case StepKind::Conv: {
-            ConvArgs a;
-            a.in = make_arg(pi, s.in);
-            a.out = make_arg(pi, s.out);
-            a.w = wp(s.w_off);
-            a.w16 = d_weights16_ && s.w_off >= 0 ? static_cast<const char*>(d_weights16_) + s.w_off * 2 : nullptr;
-            a.bias = wp(s.bias_off);
-            a.pre_scale = wp(s.pre_scale_off);
-            a.pre_shift = wp(s.pre_shift_off);
-            a.kh = s.kh; a.kw = s.kw; a.sh = s.sh; a.sw = s.sw; a.pt = s.pt; a.pl = s.pl;
-            a.pre_relu = s.pre_relu; a.relu = s.relu;
-            a.workspace = pi.workspace;
-            a.workspace_floats = pi.workspace_floats;
-            a.counters = pi.counters;
-            a.num_counters = pi.counters ? kNumCounters : 0;
+            const ConvArgs a = MakeConvArgs(pi, s);
             if (s.algo == ConvAlgo::Naive) check(LaunchConvNaive(a, stream_), "conv_naive");
             else if (s.algo == ConvAlgo::Raster3x3) check(LaunchConvRaster3x3(a, s.tile, s.splitk, stream_), "conv3x3_raster");
+            else if (s.algo == ConvAlgo::Ws1x1) check(LaunchConvWs1x1F16(a, s.tile, stream_), "conv1x1_ws_f16");
             else if (s.in.f16) check(LaunchConvIgemmF16(a, s.tile, s.splitk, stream_), "conv_igemm_f16");
             else check(LaunchConvIgemm(a, s.tile, s.algo == ConvAlgo::IgemmVec ? 1 : 0, s.splitk, stream_), "conv_igemm");
             break;
@@ -484,6 +512,7 @@ static std::string kernel_label(const Step& s) {
     switch (s.kind) {
         case StepKind::Conv:
             if (s.algo == ConvAlgo::Naive) return "conv_naive_kernel";
+            if (s.algo == ConvAlgo::Ws1x1) return "conv1x1_ws_f16_kernel<t" + std::to_string(s.tile) + ">";
             if (s.algo == ConvAlgo::Raster3x3)
                 return "conv3x3_raster_kernel<t" + std::to_string(s.tile) + (s.splitk > 1 ? ",splitk" + std::to_string(s.splitk) : std::string()) + ">";
             return std::string(s.in.f16 ? "conv_igemm_f16_kernel<" : "conv_igemm_kernel<") + std::to_string(kIgemmTiles[s.tile].bm) + "x" +

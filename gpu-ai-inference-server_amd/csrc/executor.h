@@ -14,6 +14,7 @@
 #include <thread>
 #include <vector>
 
+#include "kernels.h"
 #include "onnx_reader.h"
 #include "plan.h"
 
@@ -110,6 +111,7 @@ private:
     // MI355X counterpart of the reference's cudnn_conv_algo_search = Exhaustive (model.cpp:886).
     void Autotune(PlanInstance& pi);
     void LaunchStep(const PlanInstance& pi, const Step& s, hipStream_t stream);
+    ConvArgs MakeConvArgs(const PlanInstance& pi, const Step& s) const;
 
     std::shared_ptr<const OnnxModel> model_;
     int device_ = 0;

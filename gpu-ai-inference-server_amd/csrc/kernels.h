@@ -25,6 +25,8 @@ struct ConvArgs {
     const float* bias = nullptr;       // [Cout] or null
     const float* pre_scale = nullptr;  // [Cin] or null: x <- x*scale + shift (then ReLU if pre_relu) before the conv
     const float* pre_shift = nullptr;
+    const void* pre_scale16 = nullptr; // half copies of pre_scale / pre_shift (fp16 precision mode, packed-half prologue)
+    const void* pre_shift16 = nullptr;
     int kh = 1, kw = 1, sh = 1, sw = 1, pt = 0, pl = 0;
     int pre_relu = 0, relu = 0;
     float* workspace = nullptr;        // split-K partial slabs (only when splitk > 1)
@@ -66,6 +68,12 @@ hipError_t LaunchConvNaive(const ConvArgs& a, hipStream_t stream);
 hipError_t LaunchSplitKReduce(const ConvArgs& a, int splitk, hipStream_t stream);
 hipError_t LaunchConvIgemmF16(const ConvArgs& a, int tile, int splitk, hipStream_t stream);
 hipError_t InitKernelsF16();
+// fp16 weights-stationary 1x1 conv (kernels_ws.hip): weights in LDS once per persistent workgroup, activations streamed
+// from HBM straight into MFMA fragments.  tile: 0..kNumConvWsTiles-1 = {output channels per workgroup, waves}.
+constexpr int kNumConvWsTiles = 6;
+bool ConvWsEligible(const ConvArgs& a, int tile);
+hipError_t LaunchConvWs1x1F16(const ConvArgs& a, int tile, hipStream_t stream);
+hipError_t InitKernelsWs();
 hipError_t LaunchConvertF32ToF16(const float* src, void* dst, int64_t n, hipStream_t stream);
 hipError_t LaunchPool(const PoolArgs& a, hipStream_t stream);
 // out[n, c] = mean over (y, x) of f(in[n, y, x, c]),  f = optional scale/shift/ReLU prologue

@@ -19,7 +19,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 template <int BM, int BN, int WM, int WN, int KG, bool PRE>
-__global__ __launch_bounds__(64 * WM * WN * KG) void conv_igemm_f16_kernel(const ConvArgs a, const int tiles_n, const int num_tiles) {
+__global__ __launch_bounds__(64 * WM * WN * KG) void conv_igemm_f16_kernel(const ConvArgs a, const int tiles_n, const int num_tiles,
+                                                                                  const int vec_store) {
     constexpr int NT = 64 * WM * WN;             // threads of one K-group
     constexpr int BKE = 64;                      // K-tile depth in halfs (128 B per row, as in the fp32 kernel)
     constexpr int LDP = BKE + 8;                 // row pitch in halfs (144 B)
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_igemm_f16_kernel(const
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[cur][j], af[cur][i], acc[i][j], 0, 0, 0);
         }
     };
 
@@ -127,8 +128,13 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_igemm_f16_kernel(const
     for (int i = 0; i < B_IT; ++i) boff[i] = (n0 + rw + i * ROWS_PER_PASS) * Ktot + c8;
 
     f32x4 ra[A_IT], rb[B_IT];
-    f32x4 s_lo = {1.f, 1.f, 1.f, 1.f}, s_hi = s_lo, t_lo = {0.f, 0.f, 0.f, 0.f}, t_hi = t_lo;
+    // BN scale/shift of the prologue as halfs (the half mirror of the blob): y = max(fma(x, s, t), 0) runs as packed half math
+    // (v_pk_fma_f16 / v_pk_max_f16, one rounding, the result is stored to LDS as half anyway) - 8 VALU per 8 channels instead
+    // of ~40 for convert / fp32 fma / max / convert, which otherwise out-costs the MFMAs of a K-tile.
+    h8 s16 = {}, t16 = {};
     unsigned okmask = 0;
+    const _Float16* const ps16 = static_cast<const _Float16*>(a.pre_scale16);
+    const _Float16* const pt16 = static_cast<const _Float16*>(a.pre_shift16);
     auto issue_loads = [&](int kt) {
         const int tap = kt / cblocks;
         const int c0 = (kt - tap * cblocks) * BKE;
@@ -138,10 +144,8 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_igemm_f16_kernel(const
         const bool cok = c0 + c8 < Cin;
         if constexpr (PRE) {
             const int cc = cok ? c0 + c8 : 0;
-            s_lo = *reinterpret_cast<const f32x4*>(a.pre_scale + cc);
-            s_hi = *reinterpret_cast<const f32x4*>(a.pre_scale + cc + 4);
-            t_lo = *reinterpret_cast<const f32x4*>(a.pre_shift + cc);
-            t_hi = *reinterpret_cast<const f32x4*>(a.pre_shift + cc + 4);
+            s16 = *reinterpret_cast<const h8*>(ps16 + cc);
+            t16 = *reinterpret_cast<const h8*>(pt16 + cc);
             okmask = 0;
         }
 #pragma unroll
@@ -163,18 +167,9 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_igemm_f16_kernel(const
             f32x4 raw = ra[i];
             if constexpr (PRE) {
                 h8 v = __builtin_bit_cast(h8, raw);
-                float f[8];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    f[e] = float(v[e]) * s_lo[e] + t_lo[e];
-                    f[e + 4] = float(v[e + 4]) * s_hi[e] + t_hi[e];
-                }
-                const bool keep = okmask & (1u << i);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float x = a.pre_relu ? fmaxf(f[e], 0.f) : f[e];
-                    v[e] = _Float16(keep ? x : 0.f);      // zero padding applies AFTER the activation
-                }
+                v = v * s16 + t16;
+                if (a.pre_relu) v = __builtin_elementwise_max(v, h8{});
+                if (!(okmask & (1u << i))) v = h8{};          // zero padding applies AFTER the activation
                 raw = __builtin_bit_cast(f32x4, v);
             }
             *reinterpret_cast<f32x4*>(sA + buf * BM * LDP + (rw + i * ROWS_PER_PASS) * LDP + c8) = raw;
@@ -228,28 +223,48 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_igemm_f16_kernel(const
     }
 
     // ---- epilogue: fp32 slab (split-K) or bias + ReLU and a half / float store ----
+    // The MFMA is issued with the operands swapped (D = W x A^T: rows = output channels, columns = pixels), so a lane owns ONE
+    // pixel (m = column r) and, per accumulator quad, FOUR consecutive channels n = 8g + 4hh + q: one 8-byte (half) or
+    // 16-byte (float) store per quad instead of four 2-/4-byte ones; lanes l and l+32 fill adjacent quads of the same pixel.
     const bool partial = nsplit > 1;
     const int opitch = partial ? Cout : int(a.out.sw);
     float* const outf = partial ? a.workspace + int64_t(split) * M * Cout : a.out.p;
     _Float16* const outh = reinterpret_cast<_Float16*>(a.out.p);
     const bool store_half = !partial && a.out.f16;
+    const bool do_relu = a.relu && !partial;
+    const bool has_bias = !partial && a.bias != nullptr;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + (wn_i * TN + j) * 32 + r;
-        const bool nok = n < Cout;
-        const float bv = (!partial && a.bias != nullptr && nok) ? a.bias[n] : 0.f;
-        const bool do_relu = a.relu && !partial;
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + (wm_i * TM + i) * 32 + r;
+        const bool mok = m < M;
+        const int64_t row = int64_t(m) * opitch;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int mb = m0 + (wm_i * TM + i) * 32 + 4 * hh;
+        for (int j = 0; j < TN; ++j) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = mb + (e & 3) + 8 * (e >> 2);
-                float v = acc[i][j][e] + bv;
-                if (do_relu) v = fmaxf(v, 0.f);
-                if (nok && m < M) {
-                    if (store_half) outh[int64_t(m) * opitch + n] = _Float16(v);
-                    else outf[int64_t(m) * opitch + n] = v;
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + (wn_i * TN + j) * 32 + 8 * g + 4 * hh;
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[q] = acc[i][j][4 * g + q] + (has_bias ? a.bias[n + q < Cout ? n + q : Cout - 1] : 0.f);
+                    if (do_relu) v[q] = fmaxf(v[q], 0.f);
+                }
+                if (!mok) continue;
+                if (vec_store && n + 3 < Cout) {
+                    if (store_half) {
+                        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                        h4 hv = {_Float16(v[0]), _Float16(v[1]), _Float16(v[2]), _Float16(v[3])};
+                        *reinterpret_cast<h4*>(outh + row + n) = hv;
+                    } else {
+                        *reinterpret_cast<f32x4*>(outf + row + n) = f32x4{v[0], v[1], v[2], v[3]};
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (n + q < Cout) {
+                            if (store_half) outh[row + n + q] = _Float16(v[q]);
+                            else outf[row + n + q] = v[q];
+                        }
                 }
             }
         }
@@ -269,8 +284,13 @@ static hipError_t launch_f16_t(const ConvArgs& a, int splitk, hipStream_t stream
     const int tiles_m = int((M + t.bm - 1) / t.bm), tiles_n = (a.out.c + t.bn - 1) / t.bn;
     const int num_tiles = tiles_m * tiles_n;
     if (splitk > 1 && (a.workspace == nullptr || int64_t(splitk) * M * a.out.c > a.workspace_floats)) return hipErrorInvalidValue;
+    // quad stores need 4-channel granularity and 8-/16-byte aligned quads in whichever buffer this launch writes
+    int vec_store;
+    if (splitk > 1) vec_store = (a.out.c % 4 == 0) && (reinterpret_cast<uintptr_t>(a.workspace) % 16 == 0);
+    else if (a.out.f16) vec_store = (a.out.c % 4 == 0) && (a.out.sw % 4 == 0) && (reinterpret_cast<uintptr_t>(a.out.p) % 8 == 0);
+    else vec_store = (a.out.c % 4 == 0) && (a.out.sw % 4 == 0) && (reinterpret_cast<uintptr_t>(a.out.p) % 16 == 0);
     conv_igemm_f16_kernel<t.bm, t.bn, t.wm, t.wn, t.kg, PRE>
-        <<<dim3(num_tiles, splitk), dim3(64 * t.wm * t.wn * t.kg), f16_lds_bytes<T>(), stream>>>(a, tiles_n, num_tiles);
+        <<<dim3(num_tiles, splitk), dim3(64 * t.wm * t.wn * t.kg), f16_lds_bytes<T>(), stream>>>(a, tiles_n, num_tiles, vec_store);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || splitk == 1) return e;
     return LaunchSplitKReduce(a, splitk, stream);
@@ -289,7 +309,9 @@ hipError_t LaunchConvIgemmF16(const ConvArgs& a_in, int tile, int splitk, hipStr
     if ((a.in.c & 7) || (a.in.sw & 7) || (a.in.sh & 7) || (a.in.sn & 7) || (reinterpret_cast<uintptr_t>(a.in.p) & 15) ||
         (reinterpret_cast<uintptr_t>(a.w16) & 15) || a.kh * a.kw > 32)
         return hipErrorInvalidValue;
-    if (a.pre_scale && ((reinterpret_cast<uintptr_t>(a.pre_scale) & 15) || (reinterpret_cast<uintptr_t>(a.pre_shift) & 15))) return hipErrorInvalidValue;
+    if (a.pre_scale && (a.pre_scale16 == nullptr || a.pre_shift16 == nullptr || (reinterpret_cast<uintptr_t>(a.pre_scale16) & 15) ||
+                        (reinterpret_cast<uintptr_t>(a.pre_shift16) & 15)))
+        return hipErrorInvalidValue;
     a.in_bytes = 2 * (int64_t(a.in.n - 1) * a.in.sn + int64_t(a.in.h - 1) * a.in.sh + int64_t(a.in.w - 1) * a.in.sw + int64_t(a.in.c - 1) + 1);
     if (a.in_bytes >= (int64_t(1) << 31) || int64_t(a.out.c) * a.kh * a.kw * a.in.c * 2 >= (int64_t(1) << 31)) return hipErrorInvalidValue;
     if (int64_t(a.out.n) * a.out.h * a.out.w * a.out.sw >= (int64_t(1) << 31) || splitk < 1 || splitk > 64) return hipErrorInvalidValue;

@@ -576,16 +576,42 @@ def test_fp16_every_tile_and_split_k(tmp_path, tile, splitk):
     assert e < F16_RTOL, (tile, splitk, e)
 
 
+@pytest.mark.parametrize("tile", range(6))
+def test_fp16_weights_stationary_1x1_kernel(tmp_path, tile):
+    """conv1x1_ws_f16_kernel (weights in LDS once per persistent workgroup, activations streamed into MFMA fragments): every
+    {channels per workgroup, waves} variant on a DenseNet whose 1x1 convs have 32-aligned input channels, half and float outputs."""
+    mb = models.densenet(3, growth=32, blocks=(2, 2), stem=32, image=40, classes=40, seed=78)
+    path = models.write_repo(str(tmp_path), "f16ws", mb)
+    om = O.load_model(mb)
+    x = models.synthetic_input((3, 3, 40, 40), stream="f16ws")
+    ref = O.run(om, {"data_0": x}, dtype=np.float64)["fc6_1"]
+
+    def go():
+        plan = B.DescribeModel(path, 3)["plan"]
+        nws = sum(1 for st in plan["steps"] if st.get("algo") == "ws1x1")
+        m = B.CreateModel(path, "f16ws")
+        try:
+            return nws, infer(m, "", "data_0", x, "fc6_1", [3, 40, 1, 1])[0]
+        finally:
+            m.Destroy()
+    nws, y = _run_with_env(_f16_env(IE_FORCE_ALGO="ws", IE_FORCE_TILE=str(tile)), go)
+    assert nws >= (3 if tile >= 2 else 2), nws
+    e = rel_err(y, ref)
+    print(f"ws tile {tile}: {nws} convs on the weights-stationary kernel, rel err {e:.2e}")
+    assert e < F16_RTOL, (tile, e)
+
+
 @pytest.mark.parametrize("seed", range(3))
 def test_fp16_random_conv_graphs_vs_oracle(tmp_path, seed):
     """Seeded random convolutions with 8-aligned channels (kernel 1..7, stride 1/2, padding, fused BN+ReLU prologue /
     epilogue, channel-offset stores into a Concat buffer) on the fp16 path: autotuned, heuristic, forced K-group tile, split-K."""
     rs = np.random.RandomState(2000 + seed)
     modes = [dict(), dict(IE_AUTOTUNE="0"), dict(IE_FORCE_ALGO="igemm", IE_FORCE_TILE=str(7 + seed)),
-             dict(IE_FORCE_ALGO="igemm", IE_FORCE_SPLITK="2", IE_FORCE_TILE=str(seed + 3)), dict(IE_FORCE_ALGO="naive")]
+             dict(IE_FORCE_ALGO="igemm", IE_FORCE_SPLITK="2", IE_FORCE_TILE=str(seed + 3)), dict(IE_FORCE_ALGO="naive"),
+             dict(IE_FORCE_ALGO="ws", IE_FORCE_TILE=str(2 * seed))]
     worst = 0.0
-    for case in range(10):
-        mb, ishape, oshape, desc = _random_conv_graph(rs, case, cin_choices=(8, 16, 24, 40, 64, 72, 96, 136))
+    for case in range(12):
+        mb, ishape, oshape, desc = _random_conv_graph(rs, case, cin_choices=(8, 16, 24, 32, 64, 72, 96, 160))
         d = models.write_repo(str(tmp_path), f"h{seed}_{case}", mb)
         om = O.load_model(mb)
         x = rs.rand(*ishape).astype(np.float32)
