@@ -122,6 +122,7 @@ DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id, 
         g_kernels_err = InitKernels();
         if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsF16();
         if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsWs();
+        if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsWs3();
     });
     check(g_kernels_err, "InitKernels");
     check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
@@ -143,7 +144,8 @@ DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id, 
             std::string tok;
             while (is >> tok && tok != ":") key.push_back(std::stoll(tok));
             int t = -1, sp = 0;
-            if ((is >> t >> sp) && ((t >= 0 && t < kNumIgemmTiles) || (t >= 100 && t < 100 + kNumConvRasterTiles) || (t >= 200 && t < 200 + kNumConvWsTiles)) &&
+            if ((is >> t >> sp) && ((t >= 0 && t < kNumIgemmTiles) || (t >= 100 && t < 100 + kNumConvRasterTiles) || (t >= 200 && t < 200 + kNumConvWsTiles) ||
+                                     (t >= 300 && t < 300 + kNumConvWs3Tiles)) &&
                 sp >= 1 && sp <= 64)
                 tune_cache_[key] = {t, sp};
         }
@@ -341,7 +343,8 @@ void DeviceModel::Autotune(PlanInstance& pi) {
             if (s.in.f16 || s.out.f16) { key.push_back(s.in.f16); key.push_back(s.out.f16); }   // fp32 signatures keep 17 entries
             auto hit = tune_cache_.find(key);
             auto apply = [&](int enc_tile, int sp) {     // tile >= 100 encodes the raster kernel, >= 200 the weights-stationary 1x1
-                if (enc_tile >= 200) { s.algo = ConvAlgo::Ws1x1; s.tile = enc_tile - 200; }
+                if (enc_tile >= 300) { s.algo = ConvAlgo::Ws3x3; s.tile = enc_tile - 300; }
+                else if (enc_tile >= 200) { s.algo = ConvAlgo::Ws1x1; s.tile = enc_tile - 200; }
                 else if (enc_tile >= 100) { s.algo = ConvAlgo::Raster3x3; s.tile = enc_tile - 100; }
                 else s.tile = enc_tile;
                 s.splitk = sp;
@@ -401,6 +404,18 @@ void DeviceModel::Autotune(PlanInstance& pi) {
                     trial.splitk = 1;
                     float ms = time_trial(trial);
                     if (ms < best) { best = ms; best_tile = 200 + t; best_split = 1; }
+                }
+            }
+            if (s.in.f16 && s.algo == ConvAlgo::IgemmVec && s.kh == 3 && s.kw == 3) {
+                ConvArgs probe = MakeConvArgs(pi, s);
+                for (int t = 0; t < kNumConvWs3Tiles; ++t) {
+                    if (!ConvWs3Eligible(probe, t)) continue;
+                    Step trial = s;
+                    trial.algo = ConvAlgo::Ws3x3;
+                    trial.tile = t;
+                    trial.splitk = 1;
+                    float ms = time_trial(trial);
+                    if (ms < best) { best = ms; best_tile = 300 + t; best_split = 1; }
                 }
             }
             for (int t = 0; t < kNumIgemmTiles; ++t) {
@@ -474,6 +489,7 @@ void DeviceModel::LaunchStep(const PlanInstance& pi, const Step& s, hipStream_t 
             if (s.algo == ConvAlgo::Naive) check(LaunchConvNaive(a, stream_), "conv_naive");
             else if (s.algo == ConvAlgo::Raster3x3) check(LaunchConvRaster3x3(a, s.tile, s.splitk, stream_), "conv3x3_raster");
             else if (s.algo == ConvAlgo::Ws1x1) check(LaunchConvWs1x1F16(a, s.tile, stream_), "conv1x1_ws_f16");
+            else if (s.algo == ConvAlgo::Ws3x3) check(LaunchConvWs3x3F16(a, s.tile, stream_), "conv3x3_ws_f16");
             else if (s.in.f16) check(LaunchConvIgemmF16(a, s.tile, s.splitk, stream_), "conv_igemm_f16");
             else check(LaunchConvIgemm(a, s.tile, s.algo == ConvAlgo::IgemmVec ? 1 : 0, s.splitk, stream_), "conv_igemm");
             break;
@@ -513,6 +529,7 @@ static std::string kernel_label(const Step& s) {
         case StepKind::Conv:
             if (s.algo == ConvAlgo::Naive) return "conv_naive_kernel";
             if (s.algo == ConvAlgo::Ws1x1) return "conv1x1_ws_f16_kernel<t" + std::to_string(s.tile) + ">";
+            if (s.algo == ConvAlgo::Ws3x3) return "conv3x3_ws_f16_kernel<t" + std::to_string(s.tile) + ">";
             if (s.algo == ConvAlgo::Raster3x3)
                 return "conv3x3_raster_kernel<t" + std::to_string(s.tile) + (s.splitk > 1 ? ",splitk" + std::to_string(s.splitk) : std::string()) + ">";
             return std::string(s.in.f16 ? "conv_igemm_f16_kernel<" : "conv_igemm_kernel<") + std::to_string(kIgemmTiles[s.tile].bm) + "x" +

@@ -74,6 +74,11 @@ constexpr int kNumConvWsTiles = 6;
 bool ConvWsEligible(const ConvArgs& a, int tile);
 hipError_t LaunchConvWs1x1F16(const ConvArgs& a, int tile, hipStream_t stream);
 hipError_t InitKernelsWs();
+// fp16 weights-stationary 3x3/s1/p1 conv (Cout <= 32, all weights of the layer resident in LDS, raster window per 64-channel slice)
+constexpr int kNumConvWs3Tiles = 4;
+bool ConvWs3Eligible(const ConvArgs& a, int tile);
+hipError_t LaunchConvWs3x3F16(const ConvArgs& a, int tile, hipStream_t stream);
+hipError_t InitKernelsWs3();
 hipError_t LaunchConvertF32ToF16(const float* src, void* dst, int64_t n, hipStream_t stream);
 hipError_t LaunchPool(const PoolArgs& a, hipStream_t stream);
 // out[n, c] = mean over (y, x) of f(in[n, y, x, c]),  f = optional scale/shift/ReLU prologue

@@ -254,4 +254,270 @@ hipError_t InitKernelsWs() {
     return hipSuccess;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Weights-stationary 3x3 / stride 1 / pad 1 convolution for the fp16 mode (DenseNet's growth convs: Cin = 128, Cout = 32).
+//
+// Same 1-D raster of the zero-padded image stack as conv3x3_raster_kernel (kernels.hip): raster index
+// p = (b*RH + y)*PW + x with PW = W + 1, RH = H + 1, and tap (ky, kx) of output position p reads raster position
+// p + (ky-1)*PW + (kx-1), so the nine taps are nine constant row shifts of ONE LDS window.  What changes for fp16:
+//   * the MFMA is 16x faster, so re-staging the 9 x 32 x Cin weights per output tile (more bytes than the tile's own
+//     activations) would dominate: the workgroups are persistent and keep ALL weights of the layer in LDS (83 KB for
+//     Cin = 128), loaded once;
+//   * activations pass through LDS once per 64-channel slice: global -> registers (prefetched while the previous step is
+//     on the matrix cores) -> one window of PR = BMp + 2*PW + 2 rows x 144 B; nine shifted fragment reads per row;
+//   * D = W x A^T: a lane owns one raster position and quads of channels, v_permlane32_swap pairs the half-waves so every
+//     lane stores 16 bytes; pad positions and positions past the raster get an out-of-range buffer offset.
+// Raster positions are decoded to pixels with exact multiply-shift division (host-computed magic numbers).
+// ------------------------------------------------------------------------------------------------------------------------
+struct Ws3Geom {
+    int PW, RH, PR, num_tiles, nslices;
+    int sh_img, sh_pw;
+    unsigned long long m_img, m_pw;
+};
+
+template <int WAVES, int TMW, int PIT>
+__global__ __launch_bounds__(64 * WAVES) void conv3x3_ws_f16_kernel(const ConvArgs a, const Ws3Geom g) {
+    constexpr int NT = 64 * WAVES, BMp = 32 * TMW * WAVES, LDP = 72, RPP = NT / 8;
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem_ws[];
+    const int NS = g.nslices, PW = g.PW, PR = g.PR;
+    _Float16* const sW = smem_ws;                                 // [9][NS][32][LDP]
+    _Float16* const sP = sW + 9 * NS * 32 * LDP;                  // [PR][LDP]
+    float* const sBias = reinterpret_cast<float*>(sP + PR * LDP); // [32]
+
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Cin = a.in.c, H = a.in.h, W = a.in.w, Cout = a.out.c;
+    const int img = g.RH * PW, Mr = a.in.n * img;
+    const int isw = int(a.in.sw), opitch = int(a.out.sw);
+
+    // raster position -> pixel index (b*H + y)*W + x, or -1 for pad rows / columns and positions outside the raster
+    auto pix_of = [&](int j) -> int {
+        if (j < 0 || j >= Mr) return -1;
+        const int b = int((static_cast<unsigned long long>(unsigned(j)) * g.m_img) >> g.sh_img);
+        const int rem = j - b * img;
+        const int y = int((static_cast<unsigned long long>(unsigned(rem)) * g.m_pw) >> g.sh_pw);
+        const int x = rem - y * PW;
+        return (y < H && x < W) ? (b * H + y) * W + x : -1;
+    };
+
+    // ---- preamble: every weight of the layer -> LDS (zero-filled past Cin / Cout), bias -> LDS ----
+    {
+        const _Float16* const w = static_cast<const _Float16*>(a.w16);
+        const int items = 9 * NS * 32 * 8;
+        for (int q = tid; q < items; q += NT) {
+            const int ck = q & 7, row = q >> 3;          // row = (tap*NS + slice)*32 + n
+            const int n = row & 31, ts = row >> 5;
+            const int tap = ts / NS, sl = ts - tap * NS;
+            const int c = sl * 64 + ck * 8;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (n < Cout && c < Cin) v = *reinterpret_cast<const u32x4*>(w + (int64_t(n) * 9 + tap) * Cin + c);
+            *reinterpret_cast<u32x4*>(sW + row * LDP + ck * 8) = v;
+        }
+        for (int q = tid; q < 32; q += NT) sBias[q] = (a.bias != nullptr && q < Cout) ? a.bias[q] : 0.f;
+    }
+
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(a.in.p, 0, int(a.in_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out =
+        __builtin_amdgcn_make_buffer_rsrc(a.out.p, 0, int((int64_t(a.out.n) * a.out.h * a.out.w - 1) * opitch * 2 + Cout * 2), 0x00020000);
+
+    f32x16 acc[TMW];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    const int c8 = (tid & 7) * 8;
+    int poff[PIT];                                     // element offset of (pixel, c8) of this thread's window rows, or -1
+    u32x4 pv[PIT];
+    auto decode_rows = [&](int tile) {
+        const int jbase = tile * BMp - PW - 1;
+#pragma unroll
+        for (int i = 0; i < PIT; ++i) {
+            const int l = (tid >> 3) + i * RPP;
+            const int pix = l < PR ? pix_of(jbase + l) : -1;
+            poff[i] = pix >= 0 ? pix * isw + c8 : -1;
+        }
+    };
+    auto issue = [&](int sl) {
+        const int c0 = sl * 64;
+        const bool cok = c0 + c8 < Cin;
+#pragma unroll
+        for (int i = 0; i < PIT; ++i) {
+            const unsigned off = (poff[i] >= 0 && cok) ? unsigned(poff[i] + c0) * 2u : OOB;
+            pv[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < PIT; ++i) {
+            const int l = (tid >> 3) + i * RPP;
+            if (l < PR) *reinterpret_cast<u32x4*>(sP + l * LDP + c8) = pv[i];
+        }
+    };
+    // nine shifted GEMMs out of LDS: 36 (tap, kk) steps, fragment reads one step ahead of the MFMAs
+    auto compute_slice = [&](int sl) {
+        const _Float16* const Abase = sP + (wave * 32 * TMW + r) * LDP + hh * 8;
+        const _Float16* const Bbase = sW + (sl * 32 + r) * LDP + hh * 8;
+        constexpr int STEPS = 36;
+        h8 af[2][TMW], bf[2];
+        auto read_step = [&](int st, int slot) {
+            const int tap = st >> 2, kk = st & 3;
+            const int shift = (tap / 3) * PW + (tap % 3);
+            const _Float16* const A = Abase + shift * LDP + kk * 16;
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) af[slot][i] = *reinterpret_cast<const h8*>(A + i * 32 * LDP);
+            bf[slot] = *reinterpret_cast<const h8*>(Bbase + tap * NS * 32 * LDP + kk * 16);
+        };
+        read_step(0, 0);
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+            const int cur = st & 1;
+            if (st + 1 < STEPS) read_step(st + 1, cur ^ 1);
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[cur], af[cur][i], acc[i], 0, 0, 0);
+        }
+    };
+    auto epilogue = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i < TMW; ++i) {
+            const int pix = pix_of(tile * BMp + (wave * TMW + i) * 32 + r);
+            const unsigned rowoff = pix >= 0 ? unsigned(pix * opitch * 2) : OOB;
+            float v[16];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(sBias + 8 * gq + 4 * hh);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float x = acc[i][4 * gq + q] + bq[q];
+                    v[4 * gq + q] = a.relu ? fmaxf(x, 0.f) : x;
+                    acc[i][4 * gq + q] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                const h4 qa = {_Float16(v[8 * gp + 0]), _Float16(v[8 * gp + 1]), _Float16(v[8 * gp + 2]), _Float16(v[8 * gp + 3])};
+                const h4 qb = {_Float16(v[8 * gp + 4]), _Float16(v[8 * gp + 5]), _Float16(v[8 * gp + 6]), _Float16(v[8 * gp + 7])};
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 xa = __builtin_bit_cast(u32x2, qa), xb = __builtin_bit_cast(u32x2, qb);
+                const auto s0 = __builtin_amdgcn_permlane32_swap(xa[0], xb[0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(xa[1], xb[1], false, false);
+                const int n = 8 * (2 * gp + hh);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rs_out, n < Cout ? rowoff + unsigned(n * 2) : OOB, 0, 0);
+            }
+        }
+    };
+
+    int tile = blockIdx.x, sl = 0;
+    if (tile < g.num_tiles) {
+        decode_rows(tile);
+        issue(0);
+    }
+    while (tile < g.num_tiles) {
+        __syncthreads();                 // every wave is done reading the previous window (first pass: nothing to wait for)
+        commit();
+        __syncthreads();                 // window (and, the first time, the weights) visible to every wave
+        // next step of this workgroup: next slice of the tile, or slice 0 of its next tile
+        int ntile = tile, nsl = sl + 1;
+        if (nsl == NS) { nsl = 0; ntile = tile + gridDim.x; }
+        if (ntile < g.num_tiles) {
+            if (ntile != tile) decode_rows(ntile);
+            issue(nsl);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        compute_slice(sl);
+        __builtin_amdgcn_sched_barrier(0);
+        if (sl == NS - 1) epilogue(tile);
+        tile = ntile;
+        sl = nsl;
+    }
+}
+
+struct Ws3Tile { int waves, tmw, pit; };
+constexpr Ws3Tile kWs3Tiles[kNumConvWs3Tiles] = {{4, 2, 12}, {4, 1, 8}, {8, 1, 6}, {2, 1, 12}};
+
+static size_t ws3_lds_bytes(int tile, int Cin, int PW) {
+    const Ws3Tile t = kWs3Tiles[tile];
+    const int NS = (Cin + 63) / 64, PR = 32 * t.tmw * t.waves + 2 * PW + 2;
+    return size_t(9 * NS * 32 + PR) * 72 * sizeof(_Float16) + 32 * sizeof(float);
+}
+
+bool ConvWs3Eligible(const ConvArgs& a, int tile) {
+    if (tile < 0 || tile >= kNumConvWs3Tiles) return false;
+    if (!a.in.f16 || !a.out.f16 || a.w16 == nullptr || a.pre_scale != nullptr) return false;
+    if (a.kh != 3 || a.kw != 3 || a.sh != 1 || a.sw != 1 || a.pt != 1 || a.pl != 1 || a.out.h != a.in.h || a.out.w != a.in.w) return false;
+    if (a.in.sc != 1 || a.out.sc != 1 || (a.in.c & 7) || (a.in.sw & 7) || (reinterpret_cast<uintptr_t>(a.in.p) & 15) ||
+        (reinterpret_cast<uintptr_t>(a.w16) & 15))
+        return false;
+    if (a.out.c > 32 || (a.out.c & 7) || (a.out.sw & 7) || (reinterpret_cast<uintptr_t>(a.out.p) & 15)) return false;
+    if (a.in.sh != a.in.sw * a.in.w || a.in.sn != a.in.sh * a.in.h) return false;          // pixel-major NHWC views
+    if (a.out.sh != a.out.sw * a.out.w || a.out.sn != a.out.sh * a.out.h) return false;
+    const int64_t Mr = int64_t(a.in.n) * (a.in.h + 1) * (a.in.w + 1), Mpix = int64_t(a.in.n) * a.in.h * a.in.w;
+    if (Mr + 4096 >= (int64_t(1) << 31) || Mpix * a.in.sw * 2 >= (int64_t(1) << 31) || Mpix * a.out.sw * 2 >= (int64_t(1) << 31)) return false;
+    const Ws3Tile t = kWs3Tiles[tile];
+    const int PR = 32 * t.tmw * t.waves + 2 * (a.in.w + 1) + 2;
+    if (PR > t.pit * (64 * t.waves / 8)) return false;                                       // register prefetch covers the window
+    return ws3_lds_bytes(tile, a.in.c, a.in.w + 1) <= size_t(160) * 1024;
+}
+
+static void magic_div(unsigned d, unsigned long long* m, int* sh) {      // floor(j / d) = (j * m) >> sh for 0 <= j < 2^31
+    int L = 0;
+    while ((1ull << L) < d) ++L;
+    *sh = 31 + L;
+    *m = ((1ull << (31 + L)) / d) + 1;
+}
+
+template <int T>
+static hipError_t launch_ws3_t(const ConvArgs& a, hipStream_t stream) {
+    constexpr Ws3Tile t = kWs3Tiles[T];
+    constexpr int BMp = 32 * t.tmw * t.waves;
+    Ws3Geom g;
+    g.PW = a.in.w + 1;
+    g.RH = a.in.h + 1;
+    g.PR = BMp + 2 * g.PW + 2;
+    g.nslices = (a.in.c + 63) / 64;
+    const int64_t Mr = int64_t(a.in.n) * g.RH * g.PW;
+    g.num_tiles = int((Mr + BMp - 1) / BMp);
+    magic_div(unsigned(g.RH * g.PW), &g.m_img, &g.sh_img);
+    magic_div(unsigned(g.PW), &g.m_pw, &g.sh_pw);
+    const size_t lds = ws3_lds_bytes(T, a.in.c, g.PW);
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+        cus = prop.multiProcessorCount;
+    }
+    int per_cu = int((size_t(160) * 1024) / lds);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
+    const int slots = cus * per_cu;
+    const int iters = (g.num_tiles + slots - 1) / slots;
+    const int gx = (g.num_tiles + iters - 1) / iters;
+    conv3x3_ws_f16_kernel<t.waves, t.tmw, t.pit><<<dim3(gx), dim3(64 * t.waves), lds, stream>>>(a, g);
+    return hipGetLastError();
+}
+
+hipError_t LaunchConvWs3x3F16(const ConvArgs& a_in, int tile, hipStream_t stream) {
+    if (!ConvWs3Eligible(a_in, tile)) return hipErrorInvalidValue;
+    ConvArgs a = a_in;
+    a.in_bytes = 2 * (int64_t(a.in.n - 1) * a.in.sn + int64_t(a.in.h - 1) * a.in.sh + int64_t(a.in.w - 1) * a.in.sw + int64_t(a.in.c - 1) + 1);
+    switch (tile) {
+        case 0: return launch_ws3_t<0>(a, stream);
+        case 1: return launch_ws3_t<1>(a, stream);
+        case 2: return launch_ws3_t<2>(a, stream);
+        case 3: return launch_ws3_t<3>(a, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t InitKernelsWs3() {
+    hipError_t e;
+#define IE_WS3(T)                                                                                                             \
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_ws_f16_kernel<kWs3Tiles[T].waves, kWs3Tiles[T].tmw, kWs3Tiles[T].pit>), \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    IE_WS3(0) IE_WS3(1) IE_WS3(2) IE_WS3(3)
+#undef IE_WS3
+    return hipSuccess;
+}
+
 }  // namespace ie

@@ -739,7 +739,15 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                         const bool eligible = vec16_ok && n.kh == 1 && n.kw == 1 && n.sh == 1 && n.sw == 1 && n.pt == 0 && n.pl == 0 && n.pb == 0 &&
                                               n.pr == 0 && s.in.c % 32 == 0 && (32 * ws_tn[t] * (s.in.c + 8) + 2 * s.in.c) * 2 + 128 * ws_tn[t] <= 160 * 1024 &&
                                               !(ws_tn[t] > 1 && N <= 32 * (ws_tn[t] / 2));
+                        static const int ws3_cfg[4][3] = {{4, 2, 12}, {4, 1, 8}, {8, 1, 6}, {2, 1, 12}};   // waves, row blocks per wave, prefetch depth
+                        const int t3 = t < 4 ? t : 0;
+                        const int64_t pr3 = 32 * ws3_cfg[t3][1] * ws3_cfg[t3][0] + 2 * (s.in.w + 1) + 2;
+                        const bool eligible3 = vec16_ok && s.out.f16 && n.kh == 3 && n.kw == 3 && n.sh == 1 && n.sw == 1 && n.pt == 1 && n.pl == 1 &&
+                                               n.pb == 1 && n.pr == 1 && !n.has_pre && N <= 32 && N % 8 == 0 && s.out.pitch % 8 == 0 && s.out.c_off % 8 == 0 &&
+                                               pr3 <= ws3_cfg[t3][2] * (64 * ws3_cfg[t3][0] / 8) &&
+                                               (9 * ((s.in.c + 63) / 64) * 32 + pr3) * 144 + 128 <= 160 * 1024;
                         if (eligible) { s.algo = ConvAlgo::Ws1x1; s.tile = t; }
+                        else if (eligible3) { s.algo = ConvAlgo::Ws3x3; s.tile = t3; }
                         else if (s.algo == ConvAlgo::Naive && vec16_ok) s.algo = ConvAlgo::IgemmVec;
                     }
                     else if (f == "raster") {
@@ -753,11 +761,11 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                             s.algo = (vec_ok || vec16_ok) ? ConvAlgo::IgemmVec : (K <= 2048 && !in16 ? ConvAlgo::IgemmScalar : ConvAlgo::Naive);
                     }
                 }
-                if (const char* ft = (s.algo == ConvAlgo::Raster3x3 || s.algo == ConvAlgo::Ws1x1) ? nullptr : std::getenv("IE_FORCE_TILE")) {
+                if (const char* ft = (s.algo == ConvAlgo::Raster3x3 || s.algo == ConvAlgo::Ws1x1 || s.algo == ConvAlgo::Ws3x3) ? nullptr : std::getenv("IE_FORCE_TILE")) {
                     int t = std::atoi(ft);
                     if (t >= 0 && t < kNumIgemmTiles && (t < kNumIgemmBaseTiles || s.algo == ConvAlgo::IgemmVec) && !(in16 && kIgemmTiles[t].deep)) s.tile = t;
                 }
-                if (s.algo != ConvAlgo::IgemmVec && s.algo != ConvAlgo::Raster3x3 && s.algo != ConvAlgo::Ws1x1 && s.tile >= kNumIgemmBaseTiles)
+                if (s.algo != ConvAlgo::IgemmVec && s.algo != ConvAlgo::Raster3x3 && s.algo != ConvAlgo::Ws1x1 && s.algo != ConvAlgo::Ws3x3 && s.tile >= kNumIgemmBaseTiles)
                     s.tile = heuristic_tile;       // K-group tiles exist for the vector path only
                 if (s.algo == ConvAlgo::Raster3x3) {
                     if (const char* fs = std::getenv("IE_FORCE_SPLITK")) {
@@ -765,7 +773,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                         if (v >= 1 && v <= 64) s.splitk = v;
                     }
                     if (s.splitk > 1) plan.workspace_floats = std::max<int64_t>(plan.workspace_floats, int64_t(s.splitk) * M * N);
-                } else if (s.algo == ConvAlgo::Ws1x1) {
+                } else if (s.algo == ConvAlgo::Ws1x1 || s.algo == ConvAlgo::Ws3x3) {
                     s.splitk = 1;
                 } else if (s.algo != ConvAlgo::Naive) {
                     // split-K when the output grid cannot fill the chip: aim for >= ~768 workgroups, keep >= 2 K-tiles
@@ -875,7 +883,7 @@ static std::string json_escape(const std::string& s) {
 
 std::string PlanToJson(const Plan& p) {
     static const char* kinds[] = {"conv", "pool", "gap", "eltwise", "copy"};
-    static const char* algos[] = {"igemm_vec", "igemm_scalar", "naive", "raster3x3", "ws1x1"};
+    static const char* algos[] = {"igemm_vec", "igemm_scalar", "naive", "raster3x3", "ws1x1", "ws3x3"};
     std::ostringstream o;
     o.precision(17);
     o << "{\"inputs\":[";

@@ -577,27 +577,30 @@ def test_fp16_every_tile_and_split_k(tmp_path, tile, splitk):
 
 
 @pytest.mark.parametrize("tile", range(6))
-def test_fp16_weights_stationary_1x1_kernel(tmp_path, tile):
-    """conv1x1_ws_f16_kernel (weights in LDS once per persistent workgroup, activations streamed into MFMA fragments): every
-    {channels per workgroup, waves} variant on a DenseNet whose 1x1 convs have 32-aligned input channels, half and float outputs."""
-    mb = models.densenet(3, growth=32, blocks=(2, 2), stem=32, image=40, classes=40, seed=78)
+@pytest.mark.parametrize("image", [40, 112])
+def test_fp16_weights_stationary_kernels(tmp_path, tile, image):
+    """conv1x1_ws_f16_kernel (weights in LDS once per persistent workgroup, activations streamed into MFMA fragments) and
+    conv3x3_ws_f16_kernel (all weights of the layer resident in LDS, raster window per 64-channel slice): every tile variant,
+    single-tile and multi-tile persistent loops (image 112 -> 28x28 and 14x14 feature maps, several raster tiles per workgroup)."""
+    mb = models.densenet(3, growth=32, blocks=(2, 2), stem=32, image=image, classes=40, seed=78)
     path = models.write_repo(str(tmp_path), "f16ws", mb)
     om = O.load_model(mb)
-    x = models.synthetic_input((3, 3, 40, 40), stream="f16ws")
+    x = models.synthetic_input((3, 3, image, image), stream="f16ws")
     ref = O.run(om, {"data_0": x}, dtype=np.float64)["fc6_1"]
 
     def go():
         plan = B.DescribeModel(path, 3)["plan"]
-        nws = sum(1 for st in plan["steps"] if st.get("algo") == "ws1x1")
+        n1 = sum(1 for st in plan["steps"] if st.get("algo") == "ws1x1")
+        n3 = sum(1 for st in plan["steps"] if st.get("algo") == "ws3x3")
         m = B.CreateModel(path, "f16ws")
         try:
-            return nws, infer(m, "", "data_0", x, "fc6_1", [3, 40, 1, 1])[0]
+            return n1, n3, infer(m, "", "data_0", x, "fc6_1", [3, 40, 1, 1])[0]
         finally:
             m.Destroy()
-    nws, y = _run_with_env(_f16_env(IE_FORCE_ALGO="ws", IE_FORCE_TILE=str(tile)), go)
-    assert nws >= (3 if tile >= 2 else 2), nws
+    n1, n3, y = _run_with_env(_f16_env(IE_FORCE_ALGO="ws", IE_FORCE_TILE=str(tile)), go)
+    assert n1 >= (3 if tile >= 2 else 2) and n3 == 4, (n1, n3)
     e = rel_err(y, ref)
-    print(f"ws tile {tile}: {nws} convs on the weights-stationary kernel, rel err {e:.2e}")
+    print(f"ws tile {tile} image {image}: {n1} 1x1 + {n3} 3x3 convs on the weights-stationary kernels, rel err {e:.2e}")
     assert e < F16_RTOL, (tile, e)
 
 
