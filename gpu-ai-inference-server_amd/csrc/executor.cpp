@@ -123,6 +123,7 @@ DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id, 
         if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsF16();
         if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsWs();
         if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsWs3();
+        if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsStem();
     });
     check(g_kernels_err, "InitKernels");
     check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
@@ -333,7 +334,7 @@ void DeviceModel::Autotune(PlanInstance& pi) {
     static const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24};
     try {
         for (Step& s : pi.plan.steps) {
-            if (s.kind != StepKind::Conv || s.algo == ConvAlgo::Naive) continue;
+            if (s.kind != StepKind::Conv || s.algo == ConvAlgo::Naive || s.algo == ConvAlgo::Stem) continue;
             const int64_t M = s.out.n * s.out.h * s.out.w, N = s.out.c;
             const int64_t bk = s.in.f16 ? 2 * kIgemmBK : kIgemmBK;
             const int64_t KT = s.algo == ConvAlgo::IgemmVec ? int64_t(s.kh) * s.kw * ((s.in.c + bk - 1) / bk)
@@ -490,6 +491,7 @@ void DeviceModel::LaunchStep(const PlanInstance& pi, const Step& s, hipStream_t 
             else if (s.algo == ConvAlgo::Raster3x3) check(LaunchConvRaster3x3(a, s.tile, s.splitk, stream_), "conv3x3_raster");
             else if (s.algo == ConvAlgo::Ws1x1) check(LaunchConvWs1x1F16(a, s.tile, stream_), "conv1x1_ws_f16");
             else if (s.algo == ConvAlgo::Ws3x3) check(LaunchConvWs3x3F16(a, s.tile, stream_), "conv3x3_ws_f16");
+            else if (s.algo == ConvAlgo::Stem) check(LaunchConvStem(a, stream_), "conv_stem");
             else if (s.in.f16) check(LaunchConvIgemmF16(a, s.tile, s.splitk, stream_), "conv_igemm_f16");
             else check(LaunchConvIgemm(a, s.tile, s.algo == ConvAlgo::IgemmVec ? 1 : 0, s.splitk, stream_), "conv_igemm");
             break;
@@ -528,6 +530,7 @@ static std::string kernel_label(const Step& s) {
     switch (s.kind) {
         case StepKind::Conv:
             if (s.algo == ConvAlgo::Naive) return "conv_naive_kernel";
+            if (s.algo == ConvAlgo::Stem) return s.out.f16 ? "conv_stem_kernel<f16>" : "conv_stem_kernel<f32>";
             if (s.algo == ConvAlgo::Ws1x1) return "conv1x1_ws_f16_kernel<t" + std::to_string(s.tile) + ">";
             if (s.algo == ConvAlgo::Ws3x3) return "conv3x3_ws_f16_kernel<t" + std::to_string(s.tile) + ">";
             if (s.algo == ConvAlgo::Raster3x3)

@@ -79,6 +79,11 @@ constexpr int kNumConvWs3Tiles = 4;
 bool ConvWs3Eligible(const ConvArgs& a, int tile);
 hipError_t LaunchConvWs3x3F16(const ConvArgs& a, int tile, hipStream_t stream);
 hipError_t InitKernelsWs3();
+// Stem conv (7x7 / stride 2 / pad 3, Cin = 3, Cout <= 64) straight from the dense NCHW fp32 graph input (kernels_stem.hip);
+// half arithmetic + half output in fp16 mode, fp32 otherwise.
+bool ConvStemEligible(const ConvArgs& a);
+hipError_t LaunchConvStem(const ConvArgs& a, hipStream_t stream);
+hipError_t InitKernelsStem();
 hipError_t LaunchConvertF32ToF16(const float* src, void* dst, int64_t n, hipStream_t stream);
 hipError_t LaunchPool(const PoolArgs& a, hipStream_t stream);
 // out[n, c] = mean over (y, x) of f(in[n, y, x, c]),  f = optional scale/shift/ReLU prologue

@@ -1,0 +1,271 @@
+// Stem convolution (DenseNet / ResNet conv1: 7x7, stride 2, pad 3, Cin = 3) straight from the graph's NCHW fp32 input.
+//
+// The generic implicit GEMM reads such an input with a scalar gather (one 4-byte element per lane per K step, an address
+// computation each): on DenseNet-121 the stem alone was 5 % of the fp32 forward and 17 % of the fp16 one.  Here a workgroup owns
+// an output tile of TH x 16 pixels, stages the (S*(TH-1)+KH) x (S*15+8) x Cin input window it needs into LDS ONCE (coalesced row
+// segments of the NCHW planes, zero-filled outside the image, prefetched into registers while the previous tile is on the
+// matrix cores) and keeps ALL weights in LDS for its whole (persistent) life.  K is ordered (c, ky, kx) with kx padded to 8
+// (zero weights), so the 8 consecutive k of an MFMA operand are 8 consecutive window columns of one (c, ky) row.
+//   fp16 mode: window and weights as halfs, v_mfma_f32_32x32x16_f16, half NHWC output.
+//   fp32 mode: float window and weights, v_mfma_f32_32x32x2_f32 (4 MFMAs per 16-byte weight fragment), float NHWC output.
+// D = W x A^T: a lane owns one output pixel and quads of channels (16-byte stores).
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace ie {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+struct StemGeom {
+    int tiles_x, tiles_y, num_tiles;
+};
+
+// T = _Float16 (fp16 mode) or float (fp32 mode)
+template <typename T, int CIN, int KH, int KW, int S, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void conv_stem_kernel(const ConvArgs a, const StemGeom g) {
+    constexpr bool HALF = sizeof(T) == 2;
+    constexpr int NT = 64 * WAVES, TW = 16, TH = 2 * WAVES;
+    constexpr int G = CIN * KH;                          // (c, ky) groups of 8 k each
+    constexpr int KP = HALF ? ((G + 1) / 2) * 16 : G * 8;   // padded K
+    constexpr int WROWS = S * (TH - 1) + KH, WCOLS = S * (TW - 1) + 8;
+    // window row pitch.  Lanes 16-31 of a row block sit one output row (S window rows) below lanes 0-15; with halfs the pitch
+    // puts them 16 banks away (S*WP*2 == 64 mod 128: conflict-free 4-byte reads).  With floats the lanes are 8 bytes apart and a
+    // 2-way conflict is unavoidable (and irrelevant beside 64-cycle MFMAs), so the pitch is just the padded width.
+    constexpr int WP = HALF ? (S == 2 ? 48 : 96) : 40;
+    static_assert(WP >= WCOLS, "window pitch too small");
+    constexpr int BP = KP + (HALF ? 8 : 4);              // weight row pitch (16-byte units odd)
+    constexpr int WIN = CIN * WROWS * WP;
+    constexpr int ELEMS = CIN * WROWS * WCOLS, PIT = (ELEMS + NT - 1) / NT;
+    constexpr unsigned OOB = 0x80000000u;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_stem[];
+    T* const sWt = reinterpret_cast<T*>(smem_stem);      // [64][BP]
+    T* const sWin = sWt + 64 * BP;                       // [2][CIN][WROWS][WP]
+    float* const sBias = reinterpret_cast<float*>(sWin + 2 * WIN);   // [64]
+
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = a.in.h, W = a.in.w, OH = a.out.h, OW = a.out.w, Cout = a.out.c;
+    const int opitch = int(a.out.sw);
+
+    // ---- preamble: weights [Cout][KH][KW][CIN] (fp32) -> sWt[n][(c*KH + ky)*8 + kx], zero padded ----
+    for (int q = tid; q < 64 * KP; q += NT) {
+        const int n = q / KP, k = q - n * KP;
+        const int gi = k >> 3, kx = k & 7;
+        const int c = gi / KH, ky = gi - c * KH;
+        float v = 0.f;
+        if (n < Cout && gi < G && kx < KW) v = a.w[((n * KH + ky) * KW + kx) * CIN + c];
+        sWt[n * BP + k] = T(v);
+    }
+    for (int q = tid; q < 64; q += NT) sBias[q] = (a.bias != nullptr && q < Cout) ? a.bias[q] : 0.f;
+
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(a.in.p, 0, int(a.in_bytes), 0x00020000);
+    const int esz = a.out.f16 ? 2 : 4;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+        a.out.p, 0, int((int64_t(a.out.n) * OH * OW - 1) * opitch * esz + Cout * esz), 0x00020000);
+
+    float pv[PIT];
+    auto issue = [&](int tile) {
+        const int b = tile / (g.tiles_x * g.tiles_y);
+        const int rem = tile - b * (g.tiles_x * g.tiles_y);
+        const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
+        const int iy0 = ty * TH * S - a.pt, ix0 = tx * TW * S - a.pl;
+#pragma unroll
+        for (int i = 0; i < PIT; ++i) {
+            const int e = tid + i * NT;
+            const int c = e / (WROWS * WCOLS), rem2 = e - c * (WROWS * WCOLS);
+            const int wy = rem2 / WCOLS, wx = rem2 - wy * WCOLS;
+            const int iy = iy0 + wy, ix = ix0 + wx;
+            const bool ok = e < ELEMS && unsigned(iy) < unsigned(H) && unsigned(ix) < unsigned(W);
+            const unsigned off = ok ? unsigned(((b * CIN + c) * H + iy) * W + ix) * 4u : OOB;
+            pv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, off, 0, 0));
+        }
+    };
+    auto commit = [&](int buf) {
+        T* const win = sWin + buf * WIN;
+#pragma unroll
+        for (int i = 0; i < PIT; ++i) {
+            const int e = tid + i * NT;
+            const int c = e / (WROWS * WCOLS), rem2 = e - c * (WROWS * WCOLS);
+            const int wy = rem2 / WCOLS, wx = rem2 - wy * WCOLS;
+            if (e < ELEMS) win[(c * WROWS + wy) * WP + wx] = T(pv[i]);
+        }
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+    const int oyl = 2 * wave + (r >> 4), oxl = r & 15;     // this lane's output pixel inside the tile
+    const int lane_base = S * oyl * WP + S * oxl;
+    auto compute = [&](int buf) {
+        const T* const win = sWin + buf * WIN + lane_base;
+        if constexpr (HALF) {
+            constexpr int KSTEPS = KP / 16;
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+                // half-wave hh takes group gi = 2*kk + hh; the pad group (gi == G) re-reads the last real one against zero weights
+                const int g0 = 2 * kk, g1 = (2 * kk + 1 < G) ? 2 * kk + 1 : G - 1;
+                const int off0 = ((g0 / KH) * WROWS + (g0 % KH)) * WP, off1 = ((g1 / KH) * WROWS + (g1 % KH)) * WP;
+                const T* const ap = win + (hh ? off1 : off0);
+                u32x4 araw;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) araw[q] = *reinterpret_cast<const unsigned*>(ap + 2 * q);
+                const h8 av = __builtin_bit_cast(h8, araw);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const h8 b = *reinterpret_cast<const h8*>(sWt + (j * 32 + r) * BP + kk * 16 + hh * 8);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, av, acc[j], 0, 0, 0);
+                }
+            }
+        } else {
+            // fp32: per (c, ky) group the half-waves take kx = 4*hh + e, e = 0..3 (one 16-byte weight fragment feeds four MFMAs)
+#pragma unroll
+            for (int gi = 0; gi < G; ++gi) {
+                const int off = ((gi / KH) * WROWS + (gi % KH)) * WP;
+                const T* const ap = win + off + 4 * hh;
+                float av[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) av[e] = float(ap[e]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(sWt + (j * 32 + r) * BP + gi * 8 + hh * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[e], av[e], acc[j], 0, 0, 0);
+                }
+            }
+        }
+    };
+    auto epilogue = [&](int tile) {
+        const int b = tile / (g.tiles_x * g.tiles_y);
+        const int rem = tile - b * (g.tiles_x * g.tiles_y);
+        const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
+        const int oy = ty * TH + oyl, ox = tx * TW + oxl;
+        const unsigned rowoff = (oy < OH && ox < OW) ? unsigned(((b * OH + oy) * OW + ox) * opitch * esz) : OOB;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float v[16];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(sBias + j * 32 + 8 * gq + 4 * hh);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float x = acc[j][4 * gq + q] + bq[q];
+                    v[4 * gq + q] = a.relu ? fmaxf(x, 0.f) : x;
+                    acc[j][4 * gq + q] = 0.f;
+                }
+            }
+            if (a.out.f16) {
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    const h4 qa = {_Float16(v[8 * gp + 0]), _Float16(v[8 * gp + 1]), _Float16(v[8 * gp + 2]), _Float16(v[8 * gp + 3])};
+                    const h4 qb = {_Float16(v[8 * gp + 4]), _Float16(v[8 * gp + 5]), _Float16(v[8 * gp + 6]), _Float16(v[8 * gp + 7])};
+                    const u32x2 xa = __builtin_bit_cast(u32x2, qa), xb = __builtin_bit_cast(u32x2, qb);
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(xa[0], xb[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(xa[1], xb[1], false, false);
+                    const int n = j * 32 + 8 * (2 * gp + hh);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rs_out, n < Cout ? rowoff + unsigned(n * 2) : OOB, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int n = j * 32 + 8 * gq + 4 * hh;
+                    const f32x4 q4 = {v[4 * gq], v[4 * gq + 1], v[4 * gq + 2], v[4 * gq + 3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q4), rs_out, n < Cout ? rowoff + unsigned(n * 4) : OOB, 0, 0);
+                }
+            }
+        }
+    };
+
+    int tile = blockIdx.x, buf = 0;
+    if (tile < g.num_tiles) {
+        issue(tile);
+        commit(0);
+    }
+    __syncthreads();                         // weights + first window visible
+    while (tile < g.num_tiles) {
+        const int ntile = tile + gridDim.x;
+        if (ntile < g.num_tiles) issue(ntile);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(buf);
+        __builtin_amdgcn_sched_barrier(0);
+        epilogue(tile);
+        if (ntile < g.num_tiles) commit(buf ^ 1);      // the other buffer: its last readers passed the previous barrier
+        __syncthreads();
+        tile = ntile;
+        buf ^= 1;
+    }
+}
+
+template <typename T, int CIN, int KH, int KW, int S, int WAVES>
+static size_t stem_lds_bytes() {
+    constexpr bool HALF = sizeof(T) == 2;
+    constexpr int TH = 2 * WAVES, G = CIN * KH;
+    constexpr int KP = HALF ? ((G + 1) / 2) * 16 : G * 8;
+    constexpr int WROWS = S * (TH - 1) + KH;
+    constexpr int WP = HALF ? (S == 2 ? 48 : 96) : 40;
+    constexpr int BP = KP + (HALF ? 8 : 4);
+    return size_t(64 * BP + 2 * CIN * WROWS * WP) * sizeof(T) + 64 * sizeof(float);
+}
+
+bool ConvStemEligible(const ConvArgs& a) {
+    // the one shape this kernel is instantiated for: 7x7 / stride 2 / pad 3 over a 3-channel dense NCHW fp32 input
+    if (a.in.f16 || a.in.c != 3 || a.kh != 7 || a.kw != 7 || a.sh != 2 || a.sw != 2 || a.pt != 3 || a.pl != 3) return false;
+    if (a.pre_scale != nullptr || a.w == nullptr) return false;
+    if (a.in.sw != 1 || a.in.sh != a.in.w || a.in.sc != int64_t(a.in.h) * a.in.w || a.in.sn != a.in.sc * a.in.c) return false;   // dense NCHW
+    if (a.out.sc != 1 || a.out.c > 64 || (a.out.c & 7) || (a.out.sw & 7) || (reinterpret_cast<uintptr_t>(a.out.p) & 15)) return false;
+    if (a.out.sh != a.out.w * a.out.sw || a.out.sn != a.out.h * a.out.sh) return false;
+    if (a.out.h != (a.in.h + 6 - 7) / 2 + 1 || a.out.w != (a.in.w + 6 - 7) / 2 + 1) return false;
+    const int64_t in_elems = int64_t(a.in.n) * 3 * a.in.h * a.in.w, out_elems = int64_t(a.out.n) * a.out.h * a.out.w * a.out.sw;
+    return in_elems * 4 < (int64_t(1) << 31) && out_elems * 4 < (int64_t(1) << 31);
+}
+
+template <typename T>
+static hipError_t launch_stem_t(const ConvArgs& a, hipStream_t stream) {
+    constexpr int WAVES = 4;
+    StemGeom g;
+    g.tiles_x = (a.out.w + 15) / 16;
+    g.tiles_y = (a.out.h + 2 * WAVES - 1) / (2 * WAVES);
+    g.num_tiles = a.out.n * g.tiles_x * g.tiles_y;
+    const size_t lds = stem_lds_bytes<T, 3, 7, 7, 2, WAVES>();
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+        cus = prop.multiProcessorCount;
+    }
+    int per_cu = int((size_t(160) * 1024) / lds);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    const int slots = cus * per_cu;
+    const int iters = (g.num_tiles + slots - 1) / slots;
+    const int gx = (g.num_tiles + iters - 1) / iters;
+    conv_stem_kernel<T, 3, 7, 7, 2, WAVES><<<dim3(gx), dim3(64 * WAVES), lds, stream>>>(a, g);
+    return hipGetLastError();
+}
+
+hipError_t LaunchConvStem(const ConvArgs& a_in, hipStream_t stream) {
+    if (!ConvStemEligible(a_in)) return hipErrorInvalidValue;
+    ConvArgs a = a_in;
+    a.in_bytes = int64_t(a.in.n) * a.in.c * a.in.h * a.in.w * 4;
+    // half arithmetic only when the result is stored as half anyway (fp16 precision mode)
+    return a.out.f16 ? launch_stem_t<_Float16>(a, stream) : launch_stem_t<float>(a, stream);
+}
+
+hipError_t InitKernelsStem() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stem_kernel<_Float16, 3, 7, 7, 2, 4>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stem_kernel<float, 3, 7, 7, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               160 * 1024);
+}
+
+}  // namespace ie

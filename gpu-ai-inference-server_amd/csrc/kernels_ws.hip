@@ -46,11 +46,24 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_ws_f16_kernel(const ConvAr
     {
         const _Float16* const w = static_cast<const _Float16*>(a.w16);
         const int k8 = K >> 3;
-        for (int idx = tid; idx < BN * k8; idx += NT) {
-            const int row = idx / k8, ck = idx - row * k8;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (n0 + row < Cout) v = *reinterpret_cast<const u32x4*>(w + int64_t(n0 + row) * K + ck * 8);
-            *reinterpret_cast<u32x4*>(sB + row * P + ck * 8) = v;
+        // U loads in flight per thread: a one-at-a-time loop would pay the L2 round trip BN*K/(8*NT) times in a row
+        constexpr int U = 8;
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(w), 0, Cout * K * 2, 0x00020000);
+        for (int idx0 = tid; idx0 < BN * k8; idx0 += U * NT) {
+            u32x4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = idx0 + u * NT;
+                const int row = idx / k8, ck = idx - row * k8;
+                const unsigned off = (idx < BN * k8 && n0 + row < Cout) ? unsigned((n0 + row) * K + ck * 8) * 2u : 0x80000000u;
+                v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = idx0 + u * NT;
+                const int row = idx / k8, ck = idx - row * k8;
+                if (idx < BN * k8) *reinterpret_cast<u32x4*>(sB + row * P + ck * 8) = v[u];
+            }
         }
         for (int idx = tid; idx < BN; idx += NT) sBias[idx] = (a.bias != nullptr && n0 + idx < Cout) ? a.bias[n0 + idx] : 0.f;
         if constexpr (PRE) {
@@ -305,14 +318,25 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_ws_f16_kernel(const ConvAr
     {
         const _Float16* const w = static_cast<const _Float16*>(a.w16);
         const int items = 9 * NS * 32 * 8;
-        for (int q = tid; q < items; q += NT) {
-            const int ck = q & 7, row = q >> 3;          // row = (tap*NS + slice)*32 + n
-            const int n = row & 31, ts = row >> 5;
-            const int tap = ts / NS, sl = ts - tap * NS;
-            const int c = sl * 64 + ck * 8;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (n < Cout && c < Cin) v = *reinterpret_cast<const u32x4*>(w + (int64_t(n) * 9 + tap) * Cin + c);
-            *reinterpret_cast<u32x4*>(sW + row * LDP + ck * 8) = v;
+        constexpr int U = 8;                             // loads in flight per thread
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(w), 0, Cout * 9 * Cin * 2, 0x00020000);
+        for (int q0 = tid; q0 < items; q0 += U * NT) {
+            u32x4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int q = q0 + u * NT;
+                const int ck = q & 7, row = q >> 3;      // row = (tap*NS + slice)*32 + n
+                const int n = row & 31, ts = row >> 5;
+                const int tap = ts / NS, sl = ts - tap * NS;
+                const int c = sl * 64 + ck * 8;
+                const unsigned off = (q < items && n < Cout && c < Cin) ? unsigned((n * 9 + tap) * Cin + c) * 2u : 0x80000000u;
+                v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int q = q0 + u * NT;
+                if (q < items) *reinterpret_cast<u32x4*>(sW + (q >> 3) * LDP + (q & 7) * 8) = v[u];
+            }
         }
         for (int q = tid; q < 32; q += NT) sBias[q] = (a.bias != nullptr && q < Cout) ? a.bias[q] : 0.f;
     }

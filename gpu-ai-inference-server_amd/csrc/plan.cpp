@@ -722,6 +722,12 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                 else if (vec_ok || vec16_ok) s.algo = ConvAlgo::IgemmVec;
                 else if (K <= 2048 && !in16) s.algo = ConvAlgo::IgemmScalar;
                 else s.algo = ConvAlgo::Naive;
+                // the stem of an image classifier (7x7 / stride 2 / pad 3 over the 3-channel NCHW graph input) has its own kernel
+                const bool stem_ok = s.in.nchw && !in16 && s.in.c == 3 && n.kh == 7 && n.kw == 7 && n.sh == 2 && n.sw == 2 && n.pt == 3 &&
+                                     n.pl == 3 && n.pb == 3 && n.pr == 3 && !n.has_pre && N <= 64 && N % 8 == 0 && s.out.pitch % 8 == 0 &&
+                                     s.out.c_off % 8 == 0 && s.in.numel() * 4 < (int64_t(1) << 31) &&
+                                     s.out.n * s.out.h * s.out.w * s.out.pitch * 4 < (int64_t(1) << 31);
+                if (stem_ok && M * N >= 2048) s.algo = ConvAlgo::Stem;
                 s.tile = choose_tile(M, N);
                 s.splitk = 1;
                 const int heuristic_tile = s.tile;
@@ -730,6 +736,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                     std::string f = fa;
                     if (f == "naive") s.algo = ConvAlgo::Naive;
                     else if (f == "scalar" && K <= 2048 && !in16) s.algo = ConvAlgo::IgemmScalar;
+                    else if (f == "igemm" && s.algo == ConvAlgo::Stem) s.algo = K <= 2048 ? ConvAlgo::IgemmScalar : ConvAlgo::Naive;
                     else if (f == "igemm" && s.algo == ConvAlgo::Naive)
                         s.algo = (vec_ok || vec16_ok) ? ConvAlgo::IgemmVec : (K <= 2048 && !in16 ? ConvAlgo::IgemmScalar : ConvAlgo::Naive);
                     else if (f == "ws") {
@@ -761,7 +768,8 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                             s.algo = (vec_ok || vec16_ok) ? ConvAlgo::IgemmVec : (K <= 2048 && !in16 ? ConvAlgo::IgemmScalar : ConvAlgo::Naive);
                     }
                 }
-                if (const char* ft = (s.algo == ConvAlgo::Raster3x3 || s.algo == ConvAlgo::Ws1x1 || s.algo == ConvAlgo::Ws3x3) ? nullptr : std::getenv("IE_FORCE_TILE")) {
+                if (const char* ft = (s.algo == ConvAlgo::Raster3x3 || s.algo == ConvAlgo::Ws1x1 || s.algo == ConvAlgo::Ws3x3 || s.algo == ConvAlgo::Stem) ? nullptr
+                                                                                                                                          : std::getenv("IE_FORCE_TILE")) {
                     int t = std::atoi(ft);
                     if (t >= 0 && t < kNumIgemmTiles && (t < kNumIgemmBaseTiles || s.algo == ConvAlgo::IgemmVec) && !(in16 && kIgemmTiles[t].deep)) s.tile = t;
                 }
@@ -773,7 +781,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                         if (v >= 1 && v <= 64) s.splitk = v;
                     }
                     if (s.splitk > 1) plan.workspace_floats = std::max<int64_t>(plan.workspace_floats, int64_t(s.splitk) * M * N);
-                } else if (s.algo == ConvAlgo::Ws1x1 || s.algo == ConvAlgo::Ws3x3) {
+                } else if (s.algo == ConvAlgo::Ws1x1 || s.algo == ConvAlgo::Ws3x3 || s.algo == ConvAlgo::Stem) {
                     s.splitk = 1;
                 } else if (s.algo != ConvAlgo::Naive) {
                     // split-K when the output grid cannot fill the chip: aim for >= ~768 workgroups, keep >= 2 K-tiles
@@ -883,7 +891,7 @@ static std::string json_escape(const std::string& s) {
 
 std::string PlanToJson(const Plan& p) {
     static const char* kinds[] = {"conv", "pool", "gap", "eltwise", "copy"};
-    static const char* algos[] = {"igemm_vec", "igemm_scalar", "naive", "raster3x3", "ws1x1", "ws3x3"};
+    static const char* algos[] = {"igemm_vec", "igemm_scalar", "naive", "raster3x3", "ws1x1", "ws3x3", "stem"};
     std::ostringstream o;
     o.precision(17);
     o << "{\"inputs\":[";

@@ -42,7 +42,8 @@ enum class ConvAlgo : int {
     Naive = 2,        // one thread per output element (tiny or odd shapes, and on-device cross-check)
     Raster3x3 = 3,    // 3x3/s1/p1 MFMA conv with an LDS-resident input window (nine shifted GEMMs over a padded raster)
     Ws1x1 = 4,        // fp16 mode: weights-stationary 1x1/s1 conv, activations streamed from HBM into MFMA fragments
-    Ws3x3 = 5         // fp16 mode: weights-stationary 3x3/s1/p1 conv (Cout <= 32), raster window in LDS
+    Ws3x3 = 5,        // fp16 mode: weights-stationary 3x3/s1/p1 conv (Cout <= 32), raster window in LDS
+    Stem = 6          // 7x7/s2/p3 conv over the 3-channel NCHW fp32 graph input: LDS window per output tile, weights resident
 };
 
 struct Step {

@@ -51,7 +51,7 @@ def test_densenet121_plan(densenet_repo):
     # pre-activation BN+ReLU rides on the consumer conv, Conv->BN->ReLU on the producer
     b1 = [s for s in p["steps"] if s["kind"] == "conv" and s["k"] == [1, 1] and s["in"]["pitch"] == 256]
     assert all(s["pre"] and s["pre_relu"] and s["relu"] and s["bias"] for s in b1[:6])
-    assert p["steps"][0]["algo"] == "igemm_scalar" and p["steps"][0]["in"]["nchw"]      # stem reads the ABI's NCHW directly
+    assert p["steps"][0]["algo"] == "stem" and p["steps"][0]["in"]["nchw"]              # stem kernel reads the ABI's NCHW directly
     assert all(s["algo"] == "igemm_vec" for s in p["steps"][2:] if s["kind"] == "conv")
     assert p["outputs"][0]["dims"] == [32, 1000, 1, 1]
     # recycled activation buffers: far fewer buffers than tensors, working set < 256 MiB Infinity Cache + input
