@@ -122,6 +122,7 @@ DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id, 
         g_kernels_err = InitKernels();
         if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsF16();
         if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsWs();
+        if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsWs32();
         if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsWs3();
         if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsStem();
     });
@@ -394,11 +395,11 @@ void DeviceModel::Autotune(PlanInstance& pi) {
                     }
                 }
             }
-            // fp16 mode, 1x1/s1: weights-stationary streaming kernel
-            if (s.in.f16 && s.algo == ConvAlgo::IgemmVec && s.kh == 1 && s.kw == 1) {
+            // 1x1/s1: weights-stationary streaming kernel (either precision)
+            if (s.algo == ConvAlgo::IgemmVec && s.kh == 1 && s.kw == 1) {
                 ConvArgs probe = MakeConvArgs(pi, s);
                 for (int t = 0; t < kNumConvWsTiles; ++t) {
-                    if (!ConvWsEligible(probe, t)) continue;
+                    if (!(s.in.f16 ? ConvWsEligible(probe, t) : ConvWs32Eligible(probe, t))) continue;
                     Step trial = s;
                     trial.algo = ConvAlgo::Ws1x1;
                     trial.tile = t;
@@ -489,7 +490,8 @@ void DeviceModel::LaunchStep(const PlanInstance& pi, const Step& s, hipStream_t 
             const ConvArgs a = MakeConvArgs(pi, s);
             if (s.algo == ConvAlgo::Naive) check(LaunchConvNaive(a, stream_), "conv_naive");
             else if (s.algo == ConvAlgo::Raster3x3) check(LaunchConvRaster3x3(a, s.tile, s.splitk, stream_), "conv3x3_raster");
-            else if (s.algo == ConvAlgo::Ws1x1) check(LaunchConvWs1x1F16(a, s.tile, stream_), "conv1x1_ws_f16");
+            else if (s.algo == ConvAlgo::Ws1x1 && s.in.f16) check(LaunchConvWs1x1F16(a, s.tile, stream_), "conv1x1_ws_f16");
+            else if (s.algo == ConvAlgo::Ws1x1) check(LaunchConvWs1x1F32(a, s.tile, stream_), "conv1x1_ws_f32");
             else if (s.algo == ConvAlgo::Ws3x3) check(LaunchConvWs3x3F16(a, s.tile, stream_), "conv3x3_ws_f16");
             else if (s.algo == ConvAlgo::Stem) check(LaunchConvStem(a, stream_), "conv_stem");
             else if (s.in.f16) check(LaunchConvIgemmF16(a, s.tile, s.splitk, stream_), "conv_igemm_f16");
@@ -531,7 +533,7 @@ static std::string kernel_label(const Step& s) {
         case StepKind::Conv:
             if (s.algo == ConvAlgo::Naive) return "conv_naive_kernel";
             if (s.algo == ConvAlgo::Stem) return s.out.f16 ? "conv_stem_kernel<f16>" : "conv_stem_kernel<f32>";
-            if (s.algo == ConvAlgo::Ws1x1) return "conv1x1_ws_f16_kernel<t" + std::to_string(s.tile) + ">";
+            if (s.algo == ConvAlgo::Ws1x1) return std::string(s.in.f16 ? "conv1x1_ws_f16_kernel<t" : "conv1x1_ws_f32_kernel<t") + std::to_string(s.tile) + ">";
             if (s.algo == ConvAlgo::Ws3x3) return "conv3x3_ws_f16_kernel<t" + std::to_string(s.tile) + ">";
             if (s.algo == ConvAlgo::Raster3x3)
                 return "conv3x3_raster_kernel<t" + std::to_string(s.tile) + (s.splitk > 1 ? ",splitk" + std::to_string(s.splitk) : std::string()) + ">";

@@ -69,11 +69,16 @@ hipError_t LaunchSplitKReduce(const ConvArgs& a, int splitk, hipStream_t stream)
 hipError_t LaunchConvIgemmF16(const ConvArgs& a, int tile, int splitk, hipStream_t stream);
 hipError_t InitKernelsF16();
 // fp16 weights-stationary 1x1 conv (kernels_ws.hip): weights in LDS once per persistent workgroup, activations streamed
-// from HBM straight into MFMA fragments.  tile: 0..kNumConvWsTiles-1 = {output channels per workgroup, waves}.
-constexpr int kNumConvWsTiles = 6;
+// from HBM straight into MFMA fragments.  tile % 6 = {output channels per workgroup, waves}; tile / 6 = 0: persistent workgroups
+// with an even number of row blocks per wave, 1: one row block per wave (the hardware's workgroup dispatch balances the load).
+constexpr int kNumConvWsTiles = 12;
 bool ConvWsEligible(const ConvArgs& a, int tile);
 hipError_t LaunchConvWs1x1F16(const ConvArgs& a, int tile, hipStream_t stream);
 hipError_t InitKernelsWs();
+// fp32 twin (kernels_ws32.hip): same tile table, v_mfma_f32_32x32x2_f32, float in / float out
+bool ConvWs32Eligible(const ConvArgs& a, int tile);
+hipError_t LaunchConvWs1x1F32(const ConvArgs& a, int tile, hipStream_t stream);
+hipError_t InitKernelsWs32();
 // fp16 weights-stationary 3x3/s1/p1 conv (Cout <= 32, all weights of the layer resident in LDS, raster window per 64-channel slice)
 constexpr int kNumConvWs3Tiles = 4;
 bool ConvWs3Eligible(const ConvArgs& a, int tile);

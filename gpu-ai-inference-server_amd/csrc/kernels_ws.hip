@@ -42,6 +42,30 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_ws_f16_kernel(const ConvAr
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
+    const int nrb = (M + 31) >> 5;                    // 32-pixel row blocks
+    const int stride = gridDim.x * WAVES;
+    const int CH = K >> 5;                            // 32-channel chunks per row block
+    const int ipitch = int(a.in.sw);
+    constexpr unsigned OOB = 0x80000000u;
+
+    // load stream (rb_l, c_l) runs D chunks ahead of the compute stream (rb_c, c_c)
+    int rb_l = blockIdx.x * WAVES + wave, c_l = 0;
+    int rb_c = rb_l, c_c = 0;
+    // Ring of register chunks with STATIC slots (the chunk loop below is unrolled by D, so the compiler's waitcnt pass sees the
+    // loads in issue order and waits with exact counts, vmcnt(2(D-1)), instead of draining the ring).
+    u32x4 ring[D][2];
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(a.in.p, 0, int(a.in_bytes), 0x00020000);
+    auto issue = [&](int slot) {
+        const int m = rb_l * 32 + r;
+        const unsigned off = (rb_l < nrb && m < M) ? unsigned(m * ipitch + c_l * 32 + hh * 8) * 2u : OOB;
+        ring[slot][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0);
+        ring[slot][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off + 32u, 0, 0);
+        if (++c_l == CH) { c_l = 0; rb_l += stride; }
+    };
+    // the first D chunks are requested before the weight preamble: their HBM latency overlaps it
+#pragma unroll
+    for (int s = 0; s < D; ++s) issue(s);
+
     // ---- preamble: weight slice (and BN scale/shift) -> LDS, once per workgroup ----
     {
         const _Float16* const w = static_cast<const _Float16*>(a.w16);
@@ -77,48 +101,44 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_ws_f16_kernel(const ConvAr
     }
     __syncthreads();
 
-    const int nrb = (M + 31) >> 5;                    // 32-pixel row blocks
-    const int stride = gridDim.x * WAVES;
-    const int CH = K >> 5;                            // 32-channel chunks per row block
-    const int ipitch = int(a.in.sw);
-    constexpr unsigned OOB = 0x80000000u;
-
     f32x16 acc[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 
-    // load stream (rb_l, c_l) runs D chunks ahead of the compute stream (rb_c, c_c)
-    int rb_l = blockIdx.x * WAVES + wave, c_l = 0;
-    int rb_c = rb_l, c_c = 0;
-    // Ring of register chunks with STATIC slots (the chunk loop below is unrolled by D, so the compiler's waitcnt pass sees the
-    // loads in issue order and waits with exact counts, vmcnt(2(D-1)), instead of draining the ring).
-    u32x4 ring[D][2];
-    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(a.in.p, 0, int(a.in_bytes), 0x00020000);
-    auto issue = [&](int slot) {
-        const int m = rb_l * 32 + r;
-        const unsigned off = (rb_l < nrb && m < M) ? unsigned(m * ipitch + c_l * 32 + hh * 8) * 2u : OOB;
-        ring[slot][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0);
-        ring[slot][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off + 32u, 0, 0);
-        if (++c_l == CH) { c_l = 0; rb_l += stride; }
-    };
+    // weight fragments are read one (kk, j) step ahead of the MFMA that consumes them (LDS latency behind the previous MFMA)
     auto compute = [&](const u32x4 c0, const u32x4 c1) {
         const int cbase = c_c * 32 + hh * 8;
+        const _Float16* const Bp = sB + r * P + cbase;
+        h8 bfr[2];
+        bfr[0] = *reinterpret_cast<const h8*>(Bp);
+        h8 av[2] = {__builtin_bit_cast(h8, c0), __builtin_bit_cast(h8, c1)};
+        if constexpr (PRE) {
+            h8 s[2], t[2];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            h8 av = __builtin_bit_cast(h8, kk == 0 ? c0 : c1);
-            if constexpr (PRE) {
-                const h8 s = *reinterpret_cast<const h8*>(sS + cbase + kk * 16);
-                const h8 t = *reinterpret_cast<const h8*>(sT + cbase + kk * 16);
-                av = av * s + t;
-                if (a.pre_relu) av = __builtin_elementwise_max(av, h8{});
+            for (int kk = 0; kk < 2; ++kk) {
+                s[kk] = *reinterpret_cast<const h8*>(sS + cbase + kk * 16);
+                t[kk] = *reinterpret_cast<const h8*>(sT + cbase + kk * 16);
             }
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const h8 b = *reinterpret_cast<const h8*>(sB + (j * 32 + r) * P + cbase + kk * 16);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, av, acc[j], 0, 0, 0);
+            for (int kk = 0; kk < 2; ++kk) {
+                av[kk] = av[kk] * s[kk] + t[kk];
+                if (a.pre_relu) av[kk] = __builtin_elementwise_max(av[kk], h8{});
             }
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, PRE ? 5 : 1, 0);      // the reads above go first
+#pragma unroll
+        for (int st = 0; st < 2 * TN; ++st) {
+            const int kk = st / TN, j = st % TN;
+            if (st + 1 < 2 * TN) {
+                const int k1 = (st + 1) / TN, j1 = (st + 1) % TN;
+                bfr[(st + 1) & 1] = *reinterpret_cast<const h8*>(Bp + j1 * 32 * P + k1 * 16);
+            }
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bfr[st & 1], av[kk], acc[j], 0, 0, 0);
+            // pin the order "next fragment read, then this step's MFMA" (the scheduler otherwise sinks the read to its use)
+            if (st + 1 < 2 * TN) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
     };
     // Stores go through a buffer descriptor with 32-bit offsets: rows past M and channels past Cout get an out-of-range
@@ -170,8 +190,6 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_ws_f16_kernel(const ConvAr
         }
     };
 
-#pragma unroll
-    for (int s = 0; s < D; ++s) issue(s);
     // The ring slot is wave-uniform: a scalar jump copies the slot's registers to the operand registers (the load has to
     // have landed by then anyway) and another one re-issues into the slot, so the MFMA body and the epilogue exist once.
     // Row blocks end wherever the chunk count says (CH need not divide D), so the epilogue is inlined behind a wave-uniform
@@ -192,7 +210,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_ws_f16_kernel(const ConvAr
 }
 
 struct WsTile { int tn, waves; };
-constexpr WsTile kWsTiles[kNumConvWsTiles] = {{4, 8}, {4, 4}, {2, 8}, {2, 4}, {1, 8}, {1, 4}};
+constexpr WsTile kWsTiles[6] = {{4, 8}, {4, 4}, {2, 8}, {2, 4}, {1, 8}, {1, 4}};
 
 static size_t ws_lds_bytes(int tn, int K) { return size_t(32 * tn * (K + 8) + 2 * K) * sizeof(_Float16) + size_t(32 * tn) * sizeof(float); }
 
@@ -211,14 +229,14 @@ bool ConvWsEligible(const ConvArgs& a, int tile) {
     // 16-byte stores: 8 halfs / 4 floats per lane
     if (a.out.f16 ? ((a.out.c % 8) || (a.out.sw % 8)) : ((a.out.c % 4) || (a.out.sw % 4))) return false;
     if (reinterpret_cast<uintptr_t>(a.out.p) % 16) return false;
-    const WsTile t = kWsTiles[tile];
+    const WsTile t = kWsTiles[tile % 6];
     if (ws_lds_bytes(t.tn, a.in.c) > size_t(160) * 1024) return false;
     if (t.tn > 1 && a.out.c <= 32 * (t.tn / 2)) return false;                               // do not waste MFMA rows on padding
     return true;
 }
 
 template <int TN, int WAVES, bool PRE>
-static hipError_t launch_ws_t(const ConvArgs& a, hipStream_t stream) {
+static hipError_t launch_ws_t(const ConvArgs& a, bool one_per_wave, hipStream_t stream) {
     const int64_t M = int64_t(a.in.n) * a.in.h * a.in.w;
     const int nrb = int((M + 31) / 32);
     const size_t lds = ws_lds_bytes(TN, a.in.c);
@@ -233,11 +251,12 @@ static hipError_t launch_ws_t(const ConvArgs& a, hipStream_t stream) {
     int per_cu = int((size_t(160) * 1024) / lds);
     per_cu = per_cu < 1 ? 1 : (per_cu > 2048 / (64 * WAVES) ? 2048 / (64 * WAVES) : per_cu);
     if (per_cu > 4) per_cu = 4;
-    const int slots = cus * per_cu;
-    const int iters = (nrb + slots * WAVES - 1) / (slots * WAVES);
+    const int gy = (a.out.c + 32 * TN - 1) / (32 * TN);
+    int slots = cus * per_cu / gy;           // the resident workgroups are shared by the gy N-tiles
+    if (slots < 8) slots = 8;
+    const int iters = one_per_wave ? 1 : (nrb + slots * WAVES - 1) / (slots * WAVES);
     int gx = (nrb + iters * WAVES - 1) / (iters * WAVES);
     gx = (gx + 7) & ~7;                      // same x -> same XCD for the N-tiles of one row range
-    const int gy = (a.out.c + 32 * TN - 1) / (32 * TN);
     conv1x1_ws_f16_kernel<TN, WAVES, PRE><<<dim3(gx, gy), dim3(64 * WAVES), lds, stream>>>(a);
     return hipGetLastError();
 }
@@ -247,8 +266,8 @@ hipError_t LaunchConvWs1x1F16(const ConvArgs& a_in, int tile, hipStream_t stream
     ConvArgs a = a_in;
     a.in_bytes = 2 * (int64_t(a.in.n - 1) * a.in.sn + int64_t(a.in.h - 1) * a.in.sh + int64_t(a.in.w - 1) * a.in.sw + int64_t(a.in.c - 1) + 1);
 #define IE_WS(T, TN, W) \
-    case T: return a.pre_scale ? launch_ws_t<TN, W, true>(a, stream) : launch_ws_t<TN, W, false>(a, stream);
-    switch (tile) {
+    case T: return a.pre_scale ? launch_ws_t<TN, W, true>(a, tile >= 6, stream) : launch_ws_t<TN, W, false>(a, tile >= 6, stream);
+    switch (tile % 6) {
         IE_WS(0, 4, 8) IE_WS(1, 4, 4) IE_WS(2, 2, 8) IE_WS(3, 2, 4) IE_WS(4, 1, 8) IE_WS(5, 1, 4)
         default: return hipErrorInvalidValue;
     }

@@ -741,19 +741,22 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                         s.algo = (vec_ok || vec16_ok) ? ConvAlgo::IgemmVec : (K <= 2048 && !in16 ? ConvAlgo::IgemmScalar : ConvAlgo::Naive);
                     else if (f == "ws") {
                         int t = 0;
-                        if (const char* ft = std::getenv("IE_FORCE_TILE")) { int v = std::atoi(ft); if (v >= 0 && v < 6) t = v; }
-                        static const int ws_tn[6] = {4, 4, 2, 2, 1, 1};
+                        if (const char* ft = std::getenv("IE_FORCE_TILE")) { int v = std::atoi(ft); if (v >= 0 && v < 12) t = v; }
+                        static const int ws_tn[12] = {4, 4, 2, 2, 1, 1, 4, 4, 2, 2, 1, 1};
                         const bool eligible = vec16_ok && n.kh == 1 && n.kw == 1 && n.sh == 1 && n.sw == 1 && n.pt == 0 && n.pl == 0 && n.pb == 0 &&
                                               n.pr == 0 && s.in.c % 32 == 0 && (32 * ws_tn[t] * (s.in.c + 8) + 2 * s.in.c) * 2 + 128 * ws_tn[t] <= 160 * 1024 &&
                                               !(ws_tn[t] > 1 && N <= 32 * (ws_tn[t] / 2));
                         static const int ws3_cfg[4][3] = {{4, 2, 12}, {4, 1, 8}, {8, 1, 6}, {2, 1, 12}};   // waves, row blocks per wave, prefetch depth
-                        const int t3 = t < 4 ? t : 0;
+                        const int t3 = t % 4;
                         const int64_t pr3 = 32 * ws3_cfg[t3][1] * ws3_cfg[t3][0] + 2 * (s.in.w + 1) + 2;
                         const bool eligible3 = vec16_ok && s.out.f16 && n.kh == 3 && n.kw == 3 && n.sh == 1 && n.sw == 1 && n.pt == 1 && n.pl == 1 &&
                                                n.pb == 1 && n.pr == 1 && !n.has_pre && N <= 32 && N % 8 == 0 && s.out.pitch % 8 == 0 && s.out.c_off % 8 == 0 &&
                                                pr3 <= ws3_cfg[t3][2] * (64 * ws3_cfg[t3][0] / 8) &&
                                                (9 * ((s.in.c + 63) / 64) * 32 + pr3) * 144 + 128 <= 160 * 1024;
-                        if (eligible) { s.algo = ConvAlgo::Ws1x1; s.tile = t; }
+                        const bool eligible32 = vec_ok && !s.out.f16 && n.kh == 1 && n.kw == 1 && n.sh == 1 && n.sw == 1 && n.pt == 0 && n.pl == 0 &&
+                                                n.pb == 0 && n.pr == 0 && s.in.c % 16 == 0 && (32 * ws_tn[t] * (s.in.c + 4) + 2 * s.in.c + 32 * ws_tn[t]) * 4 <= 160 * 1024 &&
+                                                !(ws_tn[t] > 1 && N <= 32 * (ws_tn[t] / 2)) && N % 4 == 0 && s.out.pitch % 4 == 0 && s.out.c_off % 4 == 0;
+                        if (eligible || eligible32) { s.algo = ConvAlgo::Ws1x1; s.tile = t; }
                         else if (eligible3) { s.algo = ConvAlgo::Ws3x3; s.tile = t3; }
                         else if (s.algo == ConvAlgo::Naive && vec16_ok) s.algo = ConvAlgo::IgemmVec;
                     }

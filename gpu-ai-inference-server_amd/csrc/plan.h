@@ -41,7 +41,7 @@ enum class ConvAlgo : int {
     IgemmScalar = 1,  // MFMA implicit GEMM, scalar gather staging (any Cin / NCHW input, e.g. the 7x7 stem)
     Naive = 2,        // one thread per output element (tiny or odd shapes, and on-device cross-check)
     Raster3x3 = 3,    // 3x3/s1/p1 MFMA conv with an LDS-resident input window (nine shifted GEMMs over a padded raster)
-    Ws1x1 = 4,        // fp16 mode: weights-stationary 1x1/s1 conv, activations streamed from HBM into MFMA fragments
+    Ws1x1 = 4,        // weights-stationary 1x1/s1 conv (fp32 and fp16), activations streamed from HBM into MFMA fragments
     Ws3x3 = 5,        // fp16 mode: weights-stationary 3x3/s1/p1 conv (Cout <= 32), raster window in LDS
     Stem = 6          // 7x7/s2/p3 conv over the 3-channel NCHW fp32 graph input: LDS window per output tile, weights resident
 };
