@@ -125,6 +125,7 @@ DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id, 
         if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsWs32();
         if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsWs3();
         if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsStem();
+        if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsDirect();
     });
     check(g_kernels_err, "InitKernels");
     check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
@@ -147,7 +148,7 @@ DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id, 
             while (is >> tok && tok != ":") key.push_back(std::stoll(tok));
             int t = -1, sp = 0;
             if ((is >> t >> sp) && ((t >= 0 && t < kNumIgemmTiles) || (t >= 100 && t < 100 + kNumConvRasterTiles) || (t >= 200 && t < 200 + kNumConvWsTiles) ||
-                                     (t >= 300 && t < 300 + kNumConvWs3Tiles)) &&
+                                     (t >= 300 && t < 300 + kNumConvWs3Tiles) || (t >= 400 && t < 400 + kNumConvDirectTiles)) &&
                 sp >= 1 && sp <= 64)
                 tune_cache_[key] = {t, sp};
         }
@@ -345,7 +346,8 @@ void DeviceModel::Autotune(PlanInstance& pi) {
             if (s.in.f16 || s.out.f16) { key.push_back(s.in.f16); key.push_back(s.out.f16); }   // fp32 signatures keep 17 entries
             auto hit = tune_cache_.find(key);
             auto apply = [&](int enc_tile, int sp) {     // tile >= 100 encodes the raster kernel, >= 200 the weights-stationary 1x1
-                if (enc_tile >= 300) { s.algo = ConvAlgo::Ws3x3; s.tile = enc_tile - 300; }
+                if (enc_tile >= 400) { s.algo = ConvAlgo::Direct; s.tile = enc_tile - 400; }
+                else if (enc_tile >= 300) { s.algo = ConvAlgo::Ws3x3; s.tile = enc_tile - 300; }
                 else if (enc_tile >= 200) { s.algo = ConvAlgo::Ws1x1; s.tile = enc_tile - 200; }
                 else if (enc_tile >= 100) { s.algo = ConvAlgo::Raster3x3; s.tile = enc_tile - 100; }
                 else s.tile = enc_tile;
@@ -393,6 +395,19 @@ void DeviceModel::Autotune(PlanInstance& pi) {
                         float ms = time_trial(trial);
                         if (ms < best) { best = ms; best_tile = 100 + t; best_split = sp; }
                     }
+                }
+            }
+            // small output grids: K split over the waves of a workgroup, operands straight from global memory
+            if (s.algo == ConvAlgo::IgemmVec && M <= 65536) {
+                ConvArgs probe = MakeConvArgs(pi, s);
+                for (int t = 0; t < kNumConvDirectTiles; ++t) {
+                    if (!ConvDirectEligible(probe, t)) continue;
+                    Step trial = s;
+                    trial.algo = ConvAlgo::Direct;
+                    trial.tile = t;
+                    trial.splitk = 1;
+                    float ms = time_trial(trial);
+                    if (ms < best) { best = ms; best_tile = 400 + t; best_split = 1; }
                 }
             }
             // 1x1/s1: weights-stationary streaming kernel (either precision)
@@ -494,6 +509,7 @@ void DeviceModel::LaunchStep(const PlanInstance& pi, const Step& s, hipStream_t 
             else if (s.algo == ConvAlgo::Ws1x1) check(LaunchConvWs1x1F32(a, s.tile, stream_), "conv1x1_ws_f32");
             else if (s.algo == ConvAlgo::Ws3x3) check(LaunchConvWs3x3F16(a, s.tile, stream_), "conv3x3_ws_f16");
             else if (s.algo == ConvAlgo::Stem) check(LaunchConvStem(a, stream_), "conv_stem");
+            else if (s.algo == ConvAlgo::Direct) check(LaunchConvDirect(a, s.tile, stream_), "conv_direct");
             else if (s.in.f16) check(LaunchConvIgemmF16(a, s.tile, s.splitk, stream_), "conv_igemm_f16");
             else check(LaunchConvIgemm(a, s.tile, s.algo == ConvAlgo::IgemmVec ? 1 : 0, s.splitk, stream_), "conv_igemm");
             break;
@@ -532,6 +548,7 @@ static std::string kernel_label(const Step& s) {
     switch (s.kind) {
         case StepKind::Conv:
             if (s.algo == ConvAlgo::Naive) return "conv_naive_kernel";
+            if (s.algo == ConvAlgo::Direct) return std::string(s.in.f16 ? "conv_direct_kernel<f16,t" : "conv_direct_kernel<f32,t") + std::to_string(s.tile) + ">";
             if (s.algo == ConvAlgo::Stem) return s.out.f16 ? "conv_stem_kernel<f16>" : "conv_stem_kernel<f32>";
             if (s.algo == ConvAlgo::Ws1x1) return std::string(s.in.f16 ? "conv1x1_ws_f16_kernel<t" : "conv1x1_ws_f32_kernel<t") + std::to_string(s.tile) + ">";
             if (s.algo == ConvAlgo::Ws3x3) return "conv3x3_ws_f16_kernel<t" + std::to_string(s.tile) + ">";

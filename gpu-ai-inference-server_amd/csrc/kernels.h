@@ -84,6 +84,12 @@ constexpr int kNumConvWs3Tiles = 4;
 bool ConvWs3Eligible(const ConvArgs& a, int tile);
 hipError_t LaunchConvWs3x3F16(const ConvArgs& a, int tile, hipStream_t stream);
 hipError_t InitKernelsWs3();
+// "Direct split-K" conv for small output grids (kernels_direct.hip): K split over the waves of a workgroup, both operands loaded
+// straight from global memory into MFMA fragments (all at once), partial tiles summed through LDS.  fp32 and fp16.
+constexpr int kNumConvDirectTiles = 6;
+bool ConvDirectEligible(const ConvArgs& a, int tile);
+hipError_t LaunchConvDirect(const ConvArgs& a, int tile, hipStream_t stream);
+hipError_t InitKernelsDirect();
 // Stem conv (7x7 / stride 2 / pad 3, Cin = 3, Cout <= 64) straight from the dense NCHW fp32 graph input (kernels_stem.hip);
 // half arithmetic + half output in fp16 mode, fp32 otherwise.
 bool ConvStemEligible(const ConvArgs& a);

@@ -760,6 +760,18 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                         else if (eligible3) { s.algo = ConvAlgo::Ws3x3; s.tile = t3; }
                         else if (s.algo == ConvAlgo::Naive && vec16_ok) s.algo = ConvAlgo::IgemmVec;
                     }
+                    else if (f == "direct") {
+                        int t = 0;
+                        if (const char* ft = std::getenv("IE_FORCE_TILE")) { int v = std::atoi(ft); if (v >= 0 && v < 6) t = v; }
+                        static const int dcfg[6][3] = {{1, 8, 8}, {1, 16, 4}, {1, 9, 8}, {1, 4, 8}, {1, 12, 6}, {2, 8, 4}};   // tn, waves, max chunks
+                        const int cw = in16 ? 32 : 16, al = in16 ? 8 : 4;
+                        const int64_t total = s.in.c % cw == 0 ? int64_t(n.kh) * n.kw * (s.in.c / cw) : 0;
+                        const bool eligible = (vec_ok || vec16_ok) && s.in.c % cw == 0 && s.in.pitch % al == 0 && s.in.c_off % al == 0 && N % 2 == 0 &&
+                                              s.out.pitch % 2 == 0 && s.out.c_off % 2 == 0 && total >= dcfg[t][1] && total <= dcfg[t][1] * dcfg[t][2] &&
+                                              !(dcfg[t][0] > 1 && N <= 32) && M <= 65536 && n.kh * n.kw <= 49;
+                        if (eligible) { s.algo = ConvAlgo::Direct; s.tile = t; }
+                        else if (s.algo == ConvAlgo::Naive && (vec_ok || vec16_ok)) s.algo = ConvAlgo::IgemmVec;
+                    }
                     else if (f == "raster") {
                         const bool eligible = vec_ok && n.kh == 3 && n.kw == 3 && n.sh == 1 && n.sw == 1 && n.pt == 1 && n.pl == 1 &&
                                               n.pb == 1 && n.pr == 1 && !n.has_pre;
@@ -771,12 +783,12 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                             s.algo = (vec_ok || vec16_ok) ? ConvAlgo::IgemmVec : (K <= 2048 && !in16 ? ConvAlgo::IgemmScalar : ConvAlgo::Naive);
                     }
                 }
-                if (const char* ft = (s.algo == ConvAlgo::Raster3x3 || s.algo == ConvAlgo::Ws1x1 || s.algo == ConvAlgo::Ws3x3 || s.algo == ConvAlgo::Stem) ? nullptr
+                if (const char* ft = (s.algo == ConvAlgo::Raster3x3 || s.algo == ConvAlgo::Ws1x1 || s.algo == ConvAlgo::Ws3x3 || s.algo == ConvAlgo::Stem || s.algo == ConvAlgo::Direct) ? nullptr
                                                                                                                                           : std::getenv("IE_FORCE_TILE")) {
                     int t = std::atoi(ft);
                     if (t >= 0 && t < kNumIgemmTiles && (t < kNumIgemmBaseTiles || s.algo == ConvAlgo::IgemmVec) && !(in16 && kIgemmTiles[t].deep)) s.tile = t;
                 }
-                if (s.algo != ConvAlgo::IgemmVec && s.algo != ConvAlgo::Raster3x3 && s.algo != ConvAlgo::Ws1x1 && s.algo != ConvAlgo::Ws3x3 && s.tile >= kNumIgemmBaseTiles)
+                if (s.algo != ConvAlgo::IgemmVec && s.algo != ConvAlgo::Raster3x3 && s.algo != ConvAlgo::Ws1x1 && s.algo != ConvAlgo::Ws3x3 && s.algo != ConvAlgo::Direct && s.tile >= kNumIgemmBaseTiles)
                     s.tile = heuristic_tile;       // K-group tiles exist for the vector path only
                 if (s.algo == ConvAlgo::Raster3x3) {
                     if (const char* fs = std::getenv("IE_FORCE_SPLITK")) {
@@ -784,7 +796,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                         if (v >= 1 && v <= 64) s.splitk = v;
                     }
                     if (s.splitk > 1) plan.workspace_floats = std::max<int64_t>(plan.workspace_floats, int64_t(s.splitk) * M * N);
-                } else if (s.algo == ConvAlgo::Ws1x1 || s.algo == ConvAlgo::Ws3x3 || s.algo == ConvAlgo::Stem) {
+                } else if (s.algo == ConvAlgo::Ws1x1 || s.algo == ConvAlgo::Ws3x3 || s.algo == ConvAlgo::Stem || s.algo == ConvAlgo::Direct) {
                     s.splitk = 1;
                 } else if (s.algo != ConvAlgo::Naive) {
                     // split-K when the output grid cannot fill the chip: aim for >= ~768 workgroups, keep >= 2 K-tiles
@@ -894,7 +906,7 @@ static std::string json_escape(const std::string& s) {
 
 std::string PlanToJson(const Plan& p) {
     static const char* kinds[] = {"conv", "pool", "gap", "eltwise", "copy"};
-    static const char* algos[] = {"igemm_vec", "igemm_scalar", "naive", "raster3x3", "ws1x1", "ws3x3", "stem"};
+    static const char* algos[] = {"igemm_vec", "igemm_scalar", "naive", "raster3x3", "ws1x1", "ws3x3", "stem", "direct"};
     std::ostringstream o;
     o.precision(17);
     o << "{\"inputs\":[";

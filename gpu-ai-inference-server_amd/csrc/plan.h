@@ -43,7 +43,8 @@ enum class ConvAlgo : int {
     Raster3x3 = 3,    // 3x3/s1/p1 MFMA conv with an LDS-resident input window (nine shifted GEMMs over a padded raster)
     Ws1x1 = 4,        // weights-stationary 1x1/s1 conv (fp32 and fp16), activations streamed from HBM into MFMA fragments
     Ws3x3 = 5,        // fp16 mode: weights-stationary 3x3/s1/p1 conv (Cout <= 32), raster window in LDS
-    Stem = 6          // 7x7/s2/p3 conv over the 3-channel NCHW fp32 graph input: LDS window per output tile, weights resident
+    Stem = 6,         // 7x7/s2/p3 conv over the 3-channel NCHW fp32 graph input: LDS window per output tile, weights resident
+    Direct = 7        // small output grids: K split over the waves of a workgroup, operands loaded straight into MFMA fragments
 };
 
 struct Step {

@@ -415,7 +415,7 @@ def test_random_conv_graphs_vs_oracle(tmp_path, seed):
     rs = np.random.RandomState(1000 + seed)
     modes = [dict(), dict(IE_AUTOTUNE="0"), dict(IE_FORCE_ALGO="raster"), dict(IE_FORCE_ALGO="igemm", IE_FORCE_TILE=str(7 + seed)),
              dict(IE_FORCE_ALGO="scalar", IE_FORCE_TILE=str(seed)), dict(IE_FORCE_ALGO="igemm", IE_FORCE_SPLITK="3", IE_FORCE_TILE=str(seed + 2)),
-             dict(IE_FORCE_ALGO="ws", IE_FORCE_TILE=str(seed + 1))]
+             dict(IE_FORCE_ALGO="ws", IE_FORCE_TILE=str(seed + 1)), dict(IE_FORCE_ALGO="direct", IE_FORCE_TILE=str(seed))]
     worst = 0.0
     for case in range(14):
         mb, ishape, oshape, desc = _random_conv_graph(rs, case)
@@ -513,6 +513,36 @@ def test_fp32_weights_stationary_1x1_kernel(tmp_path, tile):
     e = rel_err(y, ref)
     print(f"fp32 ws tile {tile}: {n1} convs on the weights-stationary kernel, rel err {e:.2e}")
     assert e < RTOL, (tile, e)
+
+
+@pytest.mark.parametrize("tile", range(6))
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_direct_split_k_kernel(tmp_path, tile, prec):
+    """conv_direct_kernel (small output grids: K split over the waves of a workgroup, both operands loaded straight from global
+    memory into MFMA fragments, partial tiles summed through LDS): every {channels, waves, chunks} variant, 1x1 convs with the
+    BN+ReLU prologue and 3x3 convs with zero padding, both precisions."""
+    mb = models.densenet(2, growth=32, blocks=(3, 3), stem=256, image=64, classes=24, seed=79)
+    path = models.write_repo(str(tmp_path), "direct", mb)
+    om = O.load_model(mb)
+    x = models.synthetic_input((2, 3, 64, 64), stream="direct")
+    ref = O.run(om, {"data_0": x}, dtype=np.float64)["fc6_1"]
+
+    def go():
+        plan = B.DescribeModel(path, 2)["plan"]
+        nd = sum(1 for st in plan["steps"] if st.get("algo") == "direct")
+        m = B.CreateModel(path, "direct")
+        try:
+            y, _ = infer(m, "", "data_0", x, "fc6_1", [2, 24, 1, 1])
+            y2, _ = infer(m, "", "data_0", x, "fc6_1", [2, 24, 1, 1])
+        finally:
+            m.Destroy()
+        return nd, y, y2
+    nd, y, y2 = _run_with_env(dict(IE_PRECISION=prec, IE_FORCE_ALGO="direct", IE_FORCE_TILE=str(tile)), go)
+    np.testing.assert_array_equal(y, y2)
+    e = rel_err(y, ref)
+    print(f"direct tile {tile} {prec}: {nd} convs on the direct split-K kernel, rel err {e:.2e}")
+    assert nd >= 1, nd
+    assert e < (RTOL if prec == "fp32" else F16_RTOL), (tile, prec, e)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -641,7 +671,7 @@ def test_fp16_random_conv_graphs_vs_oracle(tmp_path, seed):
     rs = np.random.RandomState(2000 + seed)
     modes = [dict(), dict(IE_AUTOTUNE="0"), dict(IE_FORCE_ALGO="igemm", IE_FORCE_TILE=str(7 + seed)),
              dict(IE_FORCE_ALGO="igemm", IE_FORCE_SPLITK="2", IE_FORCE_TILE=str(seed + 3)), dict(IE_FORCE_ALGO="naive"),
-             dict(IE_FORCE_ALGO="ws", IE_FORCE_TILE=str(2 * seed))]
+             dict(IE_FORCE_ALGO="ws", IE_FORCE_TILE=str(2 * seed)), dict(IE_FORCE_ALGO="direct", IE_FORCE_TILE=str(2 * seed + 1))]
     worst = 0.0
     for case in range(12):
         mb, ishape, oshape, desc = _random_conv_graph(rs, case, cin_choices=(8, 16, 24, 32, 64, 72, 96, 160))
