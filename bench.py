@@ -177,9 +177,10 @@ def main() -> None:
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
         traffic, traffic_src = None, None
         try:      # HBM bytes per launch from the committed PMC pass of the same command (rocprofv3 cannot run inside bench.py)
-            rounds = sorted(x for x in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", x, "traffic.json")))
+            tf = "traffic.json" if args.dtype == "f32" else "traffic_f16_b128.json"
+            rounds = sorted(x for x in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", x, tf)))
             if rounds:
-                traffic_src = os.path.join("profiles", rounds[-1], "traffic.json")
+                traffic_src = os.path.join("profiles", rounds[-1], tf)
                 traffic = json.load(open(os.path.join(ROOT, traffic_src))).get(dom, {}).get("hbm_bytes_per_launch")
         except Exception:  # noqa: BLE001
             pass
