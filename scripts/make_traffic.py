@@ -9,6 +9,7 @@ reads (MI355X_MICROARCH.md, HBM section), WRITE_SIZE is exact.  Families are ker
 import csv
 import json
 import os
+import re
 import sys
 from collections import defaultdict
 
@@ -19,6 +20,10 @@ for name, col in (("FETCH_SIZE", "FETCH_SIZE"), ("WRITE_SIZE", "WRITE_SIZE")):
     path = os.path.join(root, f"pmc_{name}{suffix}.summary.csv")
     for r in csv.DictReader(open(path)):
         k = r["kernel"].split("<")[0]
+        m = re.match(r"_ZN2ie\d+([a-z0-9_]+?)(I|E)", k)     # names the tool's demangler gave up on (_Float16 template arguments)
+        if m:
+            k = m.group(1)
+        k = k.replace("ie::", "")
         if name == "FETCH_SIZE":
             fam[k]["launches"] += int(r["dispatches"])
             fam[k]["fetch_kb_raw"] += float(r[col])
