@@ -36,16 +36,23 @@ PEAK_FP16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense fp16/bf16 matrix
 PEAK_HBM_GBS = 8000.0
 
 
-def model_dir() -> str:
+MODELS = {   # name -> (builder, input name, output name, classes, published architecture name)
+    "densenet121": ("densenet121", "data_0", "fc6_1", "DenseNet-121"),
+    "resnet50": ("resnet50", "data", "logits", "ResNet-50"),
+}
+
+
+def model_dir(model: str = "densenet121") -> str:
     from gpu_ai_inference_server_amd.modelgen import models
     root = os.environ.get("IE_BENCH_MODEL_ROOT", "/tmp/ie_bench_models")
-    path = os.path.join(root, "densenet_onnx", "1", "model.onnx")
+    name = "densenet_onnx" if model == "densenet121" else model
+    path = os.path.join(root, name, "1", "model.onnx")
     if not os.path.exists(path):
-        models.write_repo(root, "densenet_onnx", models.densenet121("N"))
-    return os.path.join(root, "densenet_onnx", "1")
+        models.write_repo(root, name, getattr(models, MODELS[model][0])("N"))
+    return os.path.join(root, name, "1")
 
 
-def cpu_baseline(sample_images: int) -> dict:
+def cpu_baseline(sample_images: int, model: str = "densenet121") -> dict:
     """Oracle (CPU restatement, numpy/OpenBLAS) on `sample_images` images of the same synthetic workload."""
     from gpu_ai_inference_server_amd.modelgen import models
     from oracle import onnx_oracle as O
@@ -54,14 +61,15 @@ def cpu_baseline(sample_images: int) -> dict:
         cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:  # noqa: BLE001
         cores = os.cpu_count() or 1
-    m = O.load_model(models.densenet121(sample_images))
+    m = O.load_model(getattr(models, MODELS[model][0])(sample_images))
     x = models.synthetic_input((sample_images, 3, 224, 224), stream="bench")
-    O.run(m, {"data_0": x[:1]})                      # warm BLAS threads / page in
+    iname = MODELS[model][1]
+    O.run(m, {iname: x[:1]})                         # warm BLAS threads / page in
     t0 = time.perf_counter()
-    O.run(m, {"data_0": x})
+    O.run(m, {iname: x})
     dt = time.perf_counter() - t0
     return {"value": round(sample_images / dt, 3), "unit": "images/sec", "cores": int(cores), "kind": "port",
-            "sample": f"{sample_images} images of the same synthetic DenseNet-121 fp32 workload, one oracle forward "
+            "sample": f"{sample_images} images of the same synthetic {MODELS[model][3]} fp32 workload, one oracle forward "
                       f"(numpy im2col + BLAS, {dt:.1f} s); stand-in for the absent ONNX Runtime CPU EP"}
 
 
@@ -74,6 +82,8 @@ def main() -> None:
     ap.add_argument("--cpu-sample", type=int, default=8, help="images for the CPU baseline (0 = skip)")
     ap.add_argument("--dtype", choices=["f32", "f16"], default="f32",
                     help="f32 = the headline (BASELINE configs[1]); f16 = the fp16 precision mode (configs[2-3], use --batch 128)")
+    ap.add_argument("--model", choices=sorted(MODELS), default="densenet121",
+                    help="densenet121 = the headline workload; resnet50 = the second model family (BASELINE configs[4]'s architecture)")
     ap.add_argument("--no-hostpath", action="store_true", help="skip the ModelInfer (PCIe-inclusive) measurement")
     args = ap.parse_args()
 
@@ -101,13 +111,14 @@ def main() -> None:
 
     # rank 0 writes the synthetic model file once; the others wait for it
     if rank == 0:
-        mdir = model_dir()
+        mdir = model_dir(args.model)
     if dist is not None:
         dist.barrier()
-    mdir = model_dir()
+    mdir = model_dir(args.model)
+    _, in_name, out_name, arch = MODELS[args.model]
 
     os.environ["IE_PRECISION"] = "fp16" if args.dtype == "f16" else "fp32"
-    model = B.CreateModel(mdir, "densenet_onnx", device_id=local_rank)
+    model = B.CreateModel(mdir, os.path.basename(os.path.dirname(mdir)), device_id=local_rank)
     Bsz = args.batch
     din, dout = B.Prepare(model, [[Bsz, 3, 224, 224]], 1)
     x = models.synthetic_input((Bsz, 3, 224, 224), stream=f"bench/rank{rank}")
@@ -155,12 +166,12 @@ def main() -> None:
     if rank == 0:
         total_images = Bsz * world * args.steps
         result = {
-            "metric": f"images/sec, DenseNet-121 {'fp32' if args.dtype == 'f32' else 'fp16'}, batch {Bsz} per GPU, device-resident inputs (+ p50 step latency)",
+            "metric": f"images/sec, {arch} {'fp32' if args.dtype == 'f32' else 'fp16'}, batch {Bsz} per GPU, device-resident inputs (+ p50 step latency)",
             "value": round(total_images / elapsed, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"DenseNet-121 {'fp32' if args.dtype == 'f32' else 'fp16 (half activations/weights, fp32 accumulate)'} batch={Bsz} per GPU, "
-                                   f"synthetic 3x224x224 inputs (BASELINE {'configs[1]' if args.dtype == 'f32' else 'configs[2]'}); "
+            "config": {"workload": f"{arch} {'fp32' if args.dtype == 'f32' else 'fp16 (half activations/weights, fp32 accumulate)'} batch={Bsz} per GPU, "
+                                   f"synthetic 3x224x224 inputs ({('BASELINE configs[1]' if args.dtype == 'f32' else 'BASELINE configs[2]') if args.model == 'densenet121' else 'second model family'}); "
                                    "synthetic ONNX graph + seeded random weights (reference model file is not in the mount)",
                        "global_batch": Bsz * world, "per_gpu_batch": Bsz, "parallelism": f"dp{world} (independent batch shards)"},
             "p50_ms": round(p50, 4),
@@ -209,8 +220,8 @@ def main() -> None:
         result["eager_forward_ms"] = round(sum(p["ms"] for p in prof), 4)
         # ---- full C-ABI call with host buffers (PCIe-inclusive; reported, never `value`) -----------------------
         if not args.no_hostpath:
-            ins = [B.TensorData("data_0", B.DataTypeFloat32, B.Shape([Bsz, 3, 224, 224]), x)]
-            outs = [B.OutputConfig("fc6_1", [Bsz, 1000, 1, 1])]
+            ins = [B.TensorData(in_name, B.DataTypeFloat32, B.Shape([Bsz, 3, 224, 224]), x)]
+            outs = [B.OutputConfig(out_name, [Bsz, 1000, 1, 1] if args.model == "densenet121" else [Bsz, 1000])]
             for _ in range(3):
                 model.Infer(ins, outs)
             hl = []
@@ -221,7 +232,7 @@ def main() -> None:
             result["modelinfer_p50_ms"] = round(float(np.percentile(hl, 50)) * 1e3, 3)
             result["modelinfer_images_per_s"] = round(Bsz / float(np.percentile(hl, 50)), 1)
         if args.cpu_sample > 0:
-            result["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+            result["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.model)
         else:
             result["cpu_baseline"] = None
     if dist is not None:

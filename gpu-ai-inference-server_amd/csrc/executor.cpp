@@ -479,6 +479,7 @@ ConvArgs DeviceModel::MakeConvArgs(const PlanInstance& pi, const Step& s) const 
     ConvArgs a;
     a.in = make_arg(pi, s.in);
     a.out = make_arg(pi, s.out);
+    if (s.has_in2) a.res = make_arg(pi, s.in2);
     a.w = wp(s.w_off);
     a.w16 = d_weights16_ && s.w_off >= 0 ? static_cast<const char*>(d_weights16_) + s.w_off * 2 : nullptr;
     a.bias = wp(s.bias_off);
@@ -502,7 +503,13 @@ void DeviceModel::LaunchStep(const PlanInstance& pi, const Step& s, hipStream_t 
     auto wp = [&](int64_t off) -> const float* { return off >= 0 ? wb + off : nullptr; };
     switch (s.kind) {
         case StepKind::Conv: {
-            const ConvArgs a = MakeConvArgs(pi, s);
+            ConvArgs a = MakeConvArgs(pi, s);
+            // A fused residual Add lives in the weights-stationary 1x1 epilogues; any other kernel runs the conv without its ReLU
+            // and adds the shortcut in place afterwards.
+            const TensorArg res = a.res;
+            const int relu = a.relu;
+            const bool split_res = res.p != nullptr && s.algo != ConvAlgo::Ws1x1;
+            if (split_res) { a.res = TensorArg(); a.relu = 0; }
             if (s.algo == ConvAlgo::Naive) check(LaunchConvNaive(a, stream_), "conv_naive");
             else if (s.algo == ConvAlgo::Raster3x3) check(LaunchConvRaster3x3(a, s.tile, s.splitk, stream_), "conv3x3_raster");
             else if (s.algo == ConvAlgo::Ws1x1 && s.in.f16) check(LaunchConvWs1x1F16(a, s.tile, stream_), "conv1x1_ws_f16");
@@ -512,6 +519,11 @@ void DeviceModel::LaunchStep(const PlanInstance& pi, const Step& s, hipStream_t 
             else if (s.algo == ConvAlgo::Direct) check(LaunchConvDirect(a, s.tile, stream_), "conv_direct");
             else if (s.in.f16) check(LaunchConvIgemmF16(a, s.tile, s.splitk, stream_), "conv_igemm_f16");
             else check(LaunchConvIgemm(a, s.tile, s.algo == ConvAlgo::IgemmVec ? 1 : 0, s.splitk, stream_), "conv_igemm");
+            if (split_res) {
+                EltArgs e;
+                e.a = a.out; e.b = res; e.out = a.out; e.relu = relu;
+                check(LaunchEltwise(e, stream_), "eltwise(residual)");
+            }
             break;
         }
         case StepKind::Pool: {

@@ -20,6 +20,7 @@ struct TensorArg {
 
 struct ConvArgs {
     TensorArg in, out;                 // out is always NHWC (sc == 1)
+    TensorArg res;                     // res.p != null: out = act(conv + bias + res), res has the output's shape (residual Add fused)
     const float* w = nullptr;          // [Cout][kh][kw][Cin]
     const void* w16 = nullptr;         // the same weights as halfs at the same element offset (fp16 precision mode)
     const float* bias = nullptr;       // [Cout] or null
@@ -57,7 +58,7 @@ struct EltArgs {
 bool SplitKWorkspaceOk(int64_t workspace_floats, int num_counters, int splitk, int64_t num_tiles, int tile_elems);
 hipError_t LaunchConvIgemm(const ConvArgs& a, int tile, int vec, int splitk, hipStream_t stream);
 // 3x3 / stride 1 / pad 1 with an LDS-resident input window (see kernels.hip).  tile: 0..kNumConvRasterTiles-1.
-constexpr int kNumConvRasterTiles = 6;
+constexpr int kNumConvRasterTiles = 8;
 bool ConvRasterEligible(const ConvArgs& a, int tile);
 int ConvRasterTileBn(int tile);
 hipError_t LaunchConvRaster3x3(const ConvArgs& a, int tile, int splitk, hipStream_t stream);

@@ -706,10 +706,12 @@ hipError_t InitKernels() {
 // Pad positions compute garbage that is never stored (1/(W+1) of the rows).
 // ------------------------------------------------------------------------------------------------
 struct RasterTile { int waves, tmw, tn; };
-constexpr int kNumRasterTiles = 6;
-constexpr RasterTile kRasterTiles[kNumRasterTiles] = {{4, 1, 1}, {4, 2, 1}, {2, 1, 1}, {1, 1, 1}, {4, 1, 2}, {4, 2, 2}};
+constexpr int kNumRasterTiles = 8;
+// 96- and 192-position tiles exist because the tile count of a layer is fixed by its raster length: different tile sizes land on
+// different fractions of the chip's resident-workgroup slots in the last round
+constexpr RasterTile kRasterTiles[kNumRasterTiles] = {{4, 1, 1}, {4, 2, 1}, {2, 1, 1}, {1, 1, 1}, {4, 1, 2}, {4, 2, 2}, {3, 1, 1}, {6, 1, 1}};
 // window float4s per thread that the register-prefetch variant holds (0 = synchronous staging only)
-constexpr int kRasterPit[kNumRasterTiles] = {8, 12, 12, 0, 8, 12};
+constexpr int kRasterPit[kNumRasterTiles] = {8, 12, 12, 0, 8, 12, 12, 8};
 
 template <int WAVES, int TMW, int TN, int PIT>
 __global__ __launch_bounds__(64 * WAVES) void conv3x3_raster_kernel(const ConvArgs a, const int PW, const int RH, const int PR,
@@ -1010,6 +1012,8 @@ hipError_t LaunchConvRaster3x3(const ConvArgs& a_in, int tile, int splitk, hipSt
         case 3: return launch_raster_t<3>(a, splitk, stream);
         case 4: return launch_raster_t<4>(a, splitk, stream);
         case 5: return launch_raster_t<5>(a, splitk, stream);
+        case 6: return launch_raster_t<6>(a, splitk, stream);
+        case 7: return launch_raster_t<7>(a, splitk, stream);
         default: return hipErrorInvalidValue;
     }
 }
@@ -1031,7 +1035,9 @@ hipError_t InitRasterKernels() {
     if ((e = init_raster_t<2>()) != hipSuccess) return e;
     if ((e = init_raster_t<3>()) != hipSuccess) return e;
     if ((e = init_raster_t<4>()) != hipSuccess) return e;
-    return init_raster_t<5>();
+    if ((e = init_raster_t<5>()) != hipSuccess) return e;
+    if ((e = init_raster_t<6>()) != hipSuccess) return e;
+    return init_raster_t<7>();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1210,9 +1216,70 @@ __global__ void eltwise_kernel(const EltArgs a, const int64_t total) {
     st_elem(a.out.p, a.out.f16, int64_t(b) * a.out.sn + int64_t(y) * a.out.sh + int64_t(x) * a.out.sw + int64_t(c) * a.out.sc, v);
 }
 
+// 16 bytes per lane (4 floats / 8 halfs of one pixel's channels) when every operand is pixel-major NHWC of one element type
+template <bool HALF>
+__global__ void eltwise_vec_kernel(const EltArgs a, const int64_t total_vec, const int cv) {
+    constexpr int V = HALF ? 8 : 4;
+    typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+    const int64_t idx = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= total_vec) return;
+    const int64_t p = idx / cv;
+    const int c = int(idx - p * cv) * V;
+    float v[V], w[V];
+    auto load = [&](const TensorArg& t, float* dst) {
+        if constexpr (HALF) {
+            const h8v x = *reinterpret_cast<const h8v*>(reinterpret_cast<const _Float16*>(t.p) + p * t.sw + c);
+#pragma unroll
+            for (int i = 0; i < V; ++i) dst[i] = float(x[i]);
+        } else {
+            const float4 x = *reinterpret_cast<const float4*>(t.p + p * t.sw + c);
+            dst[0] = x.x; dst[1] = x.y; dst[2] = x.z; dst[3] = x.w;
+        }
+    };
+    load(a.a, v);
+    if (a.scale) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) v[i] = v[i] * a.scale[c + i] + a.shift[c + i];
+    }
+    if (a.b.p) {
+        load(a.b, w);
+#pragma unroll
+        for (int i = 0; i < V; ++i) v[i] += w[i];
+    }
+    if (a.relu) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) v[i] = fmaxf(v[i], 0.f);
+    }
+    if constexpr (HALF) {
+        h8v o;
+#pragma unroll
+        for (int i = 0; i < V; ++i) o[i] = _Float16(v[i]);
+        *reinterpret_cast<h8v*>(reinterpret_cast<_Float16*>(a.out.p) + p * a.out.sw + c) = o;
+    } else {
+        *reinterpret_cast<float4*>(a.out.p + p * a.out.sw + c) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+static bool elt_vec_ok(const TensorArg& t, int f16, int V) {
+    return t.f16 == f16 && t.sc == 1 && (t.c % V) == 0 && (t.sw % V) == 0 && t.sh == t.w * t.sw && t.sn == t.h * t.sh &&
+           (reinterpret_cast<uintptr_t>(t.p) % 16) == 0;
+}
+
 hipError_t LaunchEltwise(const EltArgs& a, hipStream_t stream) {
     const int64_t total = int64_t(a.out.n) * a.out.h * a.out.w * a.out.c;
     if (total == 0) return hipSuccess;
+    {
+        const int f16 = a.out.f16, V = f16 ? 8 : 4;
+        if (elt_vec_ok(a.out, f16, V) && elt_vec_ok(a.a, f16, V) && (a.b.p == nullptr || elt_vec_ok(a.b, f16, V))) {
+            const int64_t tv = total / V;
+            const int64_t vblocks = (tv + 255) / 256;
+            if (vblocks < (int64_t(1) << 31)) {
+                if (f16) eltwise_vec_kernel<true><<<dim3(unsigned(vblocks)), dim3(256), 0, stream>>>(a, tv, a.out.c / V);
+                else eltwise_vec_kernel<false><<<dim3(unsigned(vblocks)), dim3(256), 0, stream>>>(a, tv, a.out.c / V);
+                return hipGetLastError();
+            }
+        }
+    }
     const int64_t blocks = (total + 255) / 256;
     if (blocks >= (int64_t(1) << 31)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(eltwise_kernel, dim3(unsigned(blocks)), dim3(256), 0, stream, a, total);

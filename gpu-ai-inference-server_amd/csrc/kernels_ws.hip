@@ -147,9 +147,14 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_ws_f16_kernel(const ConvAr
     const int esz = store_half ? 2 : 4;
     const int opitch = int(a.out.sw);
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out.p, 0, int((int64_t(M - 1) * opitch + Cout) * esz), 0x00020000);
+    const bool has_res = a.res.p != nullptr;        // residual Add fused into the epilogue (same element type as the output)
+    const int rpitch = int(a.res.sw);
+    const __amdgpu_buffer_rsrc_t rs_res =
+        __builtin_amdgcn_make_buffer_rsrc(has_res ? a.res.p : a.out.p, 0, has_res ? int((int64_t(M - 1) * rpitch + Cout) * esz) : 0, 0x00020000);
     auto epilogue = [&]() {
         const int m = rb_c * 32 + r;
         const unsigned rowoff = m < M ? unsigned(m * opitch * esz) : OOB;
+        const unsigned rrow = (has_res && m < M) ? unsigned(m * rpitch * esz) : OOB;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             float v[16];
@@ -160,6 +165,23 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_ws_f16_kernel(const ConvAr
                 const f32x4 bq = *reinterpret_cast<const f32x4*>(sBias + j * 32 + 8 * g + 4 * hh);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[4 * g + q] += bq[q];
+            }
+            if (has_res) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n0 + j * 32 + 8 * g + 4 * hh;
+                    const unsigned off = n < Cout ? rrow + unsigned(n * esz) : OOB;
+                    if (store_half) {
+                        typedef unsigned u32x2r __attribute__((ext_vector_type(2)));
+                        const h4 rq = __builtin_bit_cast(h4, __builtin_bit_cast(u32x2r, __builtin_amdgcn_raw_buffer_load_b64(rs_res, off, 0, 0)));
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[4 * g + q] += float(rq[q]);
+                    } else {
+                        const f32x4 rq = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, off, 0, 0));
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[4 * g + q] += rq[q];
+                    }
+                }
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -229,6 +251,10 @@ bool ConvWsEligible(const ConvArgs& a, int tile) {
     // 16-byte stores: 8 halfs / 4 floats per lane
     if (a.out.f16 ? ((a.out.c % 8) || (a.out.sw % 8)) : ((a.out.c % 4) || (a.out.sw % 4))) return false;
     if (reinterpret_cast<uintptr_t>(a.out.p) % 16) return false;
+    if (a.res.p != nullptr) {                          // fused residual: same element type and pixel-major layout as the output
+        if (a.res.f16 != a.out.f16 || a.res.sc != 1 || (a.res.sw % 4) || (reinterpret_cast<uintptr_t>(a.res.p) % 16)) return false;
+        if (a.res.sh != a.res.w * a.res.sw || a.res.sn != a.res.h * a.res.sh || M * a.res.sw * 4 >= (int64_t(1) << 31)) return false;
+    }
     const WsTile t = kWsTiles[tile % 6];
     if (ws_lds_bytes(t.tn, a.in.c) > size_t(160) * 1024) return false;
     if (t.tn > 1 && a.out.c <= 32 * (t.tn / 2)) return false;                               // do not waste MFMA rows on padding

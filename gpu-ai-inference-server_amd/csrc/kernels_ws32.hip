@@ -130,19 +130,27 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_ws_f32_kernel(const ConvAr
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         }
     };
+    const bool has_res = a.res.p != nullptr;        // residual Add fused into the epilogue (ResNet shortcuts)
+    const int rpitch = int(a.res.sw);
+    const __amdgpu_buffer_rsrc_t rs_res =
+        __builtin_amdgcn_make_buffer_rsrc(has_res ? a.res.p : a.out.p, 0, has_res ? int((int64_t(M - 1) * rpitch + Cout) * 4) : 0, 0x00020000);
     auto epilogue = [&]() {
         const int m = rb_c * 32 + r;
         const unsigned rowoff = m < M ? unsigned(m * opitch * 4) : OOB;
+        const unsigned rrow = (has_res && m < M) ? unsigned(m * rpitch * 4) : OOB;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int nl = j * 32 + 8 * g + 4 * hh;
                 const f32x4 bq = *reinterpret_cast<const f32x4*>(sBias + nl);
+                f32x4 rq = {0.f, 0.f, 0.f, 0.f};
+                if (has_res)
+                    rq = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, n0 + nl < Cout ? rrow + unsigned((n0 + nl) * 4) : OOB, 0, 0));
                 f32x4 v;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float x = acc[j][4 * g + q] + bq[q];
+                    const float x = acc[j][4 * g + q] + bq[q] + rq[q];
                     v[q] = a.relu ? fmaxf(x, 0.f) : x;
                     acc[j][4 * g + q] = 0.f;
                 }
@@ -183,6 +191,10 @@ bool ConvWs32Eligible(const ConvArgs& a, int tile) {
     const int64_t M = int64_t(a.in.n) * a.in.h * a.in.w;
     if (M * a.in.sw * 4 >= (int64_t(1) << 31) || M * a.out.sw * 4 >= (int64_t(1) << 31)) return false;
     if ((a.out.c % 4) || (a.out.sw % 4) || (reinterpret_cast<uintptr_t>(a.out.p) % 16)) return false;      // 16-byte stores
+    if (a.res.p != nullptr) {                          // fused residual: same pixel-major layout, 16-byte loads
+        if (a.res.f16 || a.res.sc != 1 || (a.res.sw % 4) || (reinterpret_cast<uintptr_t>(a.res.p) % 16)) return false;
+        if (a.res.sh != a.res.w * a.res.sw || a.res.sn != a.res.h * a.res.sh || M * a.res.sw * 4 >= (int64_t(1) << 31)) return false;
+    }
     const Ws32Tile t = kWs32Tiles[tile % 6];
     if (ws32_lds_bytes(t.tn, a.in.c) > size_t(160) * 1024) return false;
     if (t.tn > 1 && a.out.c <= 32 * (t.tn / 2)) return false;                               // do not waste MFMA rows on padding

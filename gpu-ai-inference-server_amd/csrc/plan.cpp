@@ -41,6 +41,7 @@ struct LNode {
     std::vector<float> s, t;            // affine
     bool has_pre = false, pre_relu = false, relu = false;
     std::vector<float> pre_s, pre_t;
+    int res = -1;                       // conv: value added to the result before the ReLU (fused residual Add)
     bool dead = false;
 };
 
@@ -448,7 +449,15 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                     cv.bias[o] = cv.bias[o] * b.s[o] + b.t[o];
                 }
             } else if (b.kind == L_RELU) cv.relu = true;
-            else break;
+            else if (b.kind == L_ADD && cv.res < 0) {
+                // residual shortcut: fold the Add into this conv's epilogue when the other operand already exists at this point of
+                // the schedule (its producer runs earlier); otherwise the other branch's conv picks the Add up when its turn comes
+                const int other = b.in[0] == cv.out ? b.in[1] : b.in[0];
+                const int op = L.vals[other].producer;
+                if (other == cv.out || !(L.vals[other].is_input ? false : op >= 0 && op < int(i))) break;
+                cv.res = other;
+                cv.in.push_back(other);
+            } else break;
             cv.name += "+" + b.name;
             cv.out = b.out;
             L.vals[cv.out].producer = int(i);
@@ -512,7 +521,8 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
         for (size_t v = 0; v < L.vals.size(); ++v) {
             if (!L.vals[v].is_input || !L.vals[v].input_nchw) continue;
             bool all_conv = true;
-            for (int ci : L.consumers(int(v))) if (L.nodes[ci].kind != L_CONV) all_conv = false;
+            for (int ci : L.consumers(int(v)))
+                if (L.nodes[ci].kind != L_CONV || L.nodes[ci].in[0] != int(v) || L.nodes[ci].res == int(v)) all_conv = false;
             if (all_conv && !L.vals[v].is_output) continue;
             LNode cp;
             cp.kind = L_COPY;
@@ -707,10 +717,11 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                 s.kh = n.kh; s.kw = n.kw; s.sh = n.sh; s.sw = n.sw; s.pt = n.pt; s.pl = n.pl; s.pb = n.pb; s.pr = n.pr;
                 s.w_off = push_vec(n.w);
                 if (!n.bias.empty()) s.bias_off = push_vec(n.bias);
+                if (n.res >= 0) { s.in2 = view_of(n.res); s.has_in2 = true; }
                 int64_t M = s.out.n * s.out.h * s.out.w, N = s.out.c, K = int64_t(n.kh) * n.kw * s.in.c;
                 s.flops = 2.0 * double(M) * double(N) * double(K);
                 const bool in16 = s.in.f16;
-                s.bytes = vbytes(s.in) + vbytes(s.out) + (in16 ? 2.0 : 4.0) * double(n.w.size());
+                s.bytes = vbytes(s.in) + vbytes(s.out) + (in16 ? 2.0 : 4.0) * double(n.w.size()) + (n.res >= 0 ? vbytes(s.in2) : 0.0);
                 bool vec_ok = !in16 && !s.in.nchw && s.in.c % 4 == 0 && s.in.pitch % 4 == 0 && s.in.c_off % 4 == 0 && n.kh * n.kw <= 32 &&
                               s.in.n * s.in.h * s.in.w * s.in.pitch * 4 < (int64_t(1) << 31) && int64_t(n.w.size()) * 4 < (int64_t(1) << 31);
                 // fp16 MFMA path: 16-byte chunks of 8 halfs, so channel counts / slice offsets must be multiples of 8
@@ -778,7 +789,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                         if (eligible) {
                             s.algo = ConvAlgo::Raster3x3;
                             s.tile = 0;
-                            if (const char* ft = std::getenv("IE_FORCE_TILE")) { int t = std::atoi(ft); if (t >= 0 && t < 6) s.tile = t; }
+                            if (const char* ft = std::getenv("IE_FORCE_TILE")) { int t = std::atoi(ft); if (t >= 0 && t < 8) s.tile = t; }
                         } else if (s.algo == ConvAlgo::Naive)
                             s.algo = (vec_ok || vec16_ok) ? ConvAlgo::IgemmVec : (K <= 2048 && !in16 ? ConvAlgo::IgemmScalar : ConvAlgo::Naive);
                     }
@@ -931,6 +942,7 @@ std::string PlanToJson(const Plan& p) {
         o << (i ? "," : "") << "{\"kind\":\"" << kinds[int(s.kind)] << "\",\"name\":\"" << json_escape(s.name) << "\",\"in\":";
         json_view(o, s.in);
         if (s.has_in2) { o << ",\"in2\":"; json_view(o, s.in2); }
+        if (s.kind == StepKind::Conv) o << ",\"residual\":" << (s.has_in2 ? "true" : "false");
         o << ",\"out\":"; json_view(o, s.out);
         o << ",\"k\":[" << s.kh << "," << s.kw << "],\"stride\":[" << s.sh << "," << s.sw << "],\"pads\":[" << s.pt << ","
           << s.pl << "," << s.pb << "," << s.pr << "]";

@@ -208,6 +208,49 @@ def resnet_block(batch: int | str = 2, c: int = 32, image: int = 16, seed: int =
     return gb.finish([("x", [batch, 3, image, image])], [("y", [batch, c, image // 4, image // 4])], opset=11)
 
 
+def resnet(batch: int | str = 1, *, layers: Sequence[int] = (3, 4, 6, 3), width: int = 64, image: int = 224, classes: int = 1000,
+           seed: int = 50, in_name: str = "data", out_name: str = "logits") -> bytes:
+    """ResNet-v1.5 bottleneck network (ResNet-50 with the defaults; BASELINE.json configs[4] names this architecture).
+
+    conv7x7/s2 -> BN -> ReLU -> maxpool3x3/s2 -> 4 stages of bottlenecks [1x1 -> 3x3 (stride on the 3x3) -> 1x1 (x4)] with a
+    projection shortcut (1x1/stride conv + BN) on the first block of a stage and identity shortcuts elsewhere -> global average
+    pool -> Flatten -> Gemm.  Exercises what DenseNet does not: residual Add + ReLU, strided 1x1 / 3x3 convs, Cout up to 2048,
+    Conv->BN folding without a ReLU, a Gemm classifier.  The last BN of every block gets a small gamma (as zero-init-residual
+    training leaves it) so activations stay O(1) through 16 residual additions.
+    """
+    gb = GraphBuilder("resnet", seed)
+    x = gb.conv(in_name, 3, width, 7, stride=2, pad=3, name="conv1")
+    x = gb.relu(gb.bn(x, width, name="bn1"))
+    x = gb.pool("MaxPool", x, 3, 2, pad=1)
+    cin = width
+    for si, nblocks in enumerate(layers):
+        mid = width * (2 ** si)
+        cout = mid * 4
+        for bi in range(nblocks):
+            stride = 2 if (bi == 0 and si > 0) else 1
+            tag = f"s{si + 1}b{bi + 1}"
+            y = gb.relu(gb.bn(gb.conv(x, cin, mid, 1, name=tag + "_c1"), mid, name=tag + "_bn1"))
+            y = gb.relu(gb.bn(gb.conv(y, mid, mid, 3, stride=stride, pad=1, name=tag + "_c2"), mid, name=tag + "_bn2"))
+            y = gb.bn(gb.conv(y, mid, cout, 1, name=tag + "_c3", w_scale=float(0.5 * np.sqrt(2.0 / mid))), cout, name=tag + "_bn3")
+            if bi == 0:
+                sc = gb.bn(gb.conv(x, cin, cout, 1, stride=stride, name=tag + "_proj"), cout, name=tag + "_bnp")
+            else:
+                sc = x
+            x = gb.relu(gb.simple("Add", [y, sc]))
+            cin = cout
+    x = gb.gap(x)
+    x = gb.simple("Flatten", [x], [pb.attr_int("axis", 1)])
+    wfc = rng.gaussish(seed, "fc_w", classes * cin).reshape(classes, cin) * np.float32(np.sqrt(1.0 / cin))
+    bfc = (rng.uniform(seed, "fc_b", classes) - np.float32(0.5)) * np.float32(0.2)
+    gb.simple("Gemm", [x, gb.init("fc_w", wfc.astype(np.float32)), gb.init("fc_b", bfc.astype(np.float32))],
+              [pb.attr_int("transB", 1)], out=out_name)
+    return gb.finish([(in_name, [batch, 3, image, image])], [(out_name, [batch, classes])], opset=11)
+
+
+def resnet50(batch: int | str = 1) -> bytes:
+    return resnet(batch)
+
+
 def write_repo(root: str, name: str, model_bytes: bytes, version: str = "1", config_json: str | None = None) -> str:
     d = os.path.join(root, name, version)
     os.makedirs(d, exist_ok=True)

@@ -18,9 +18,10 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-mdir = bench.model_dir()
+model_name = sys.argv[2] if len(sys.argv) > 2 else "densenet121"
+mdir = bench.model_dir(model_name)
 plan = B.DescribeModel(mdir, batch)["plan"]
-m = B.CreateModel(mdir, "densenet_onnx")
+m = B.CreateModel(mdir, os.path.basename(os.path.dirname(mdir)))
 din, dout = B.Prepare(m, [[batch, 3, 224, 224]], 1)
 B.CopyToDevice(m, din[0], models.synthetic_input((batch, 3, 224, 224), stream="prof"))
 B.RunPrepared(m, 5, True)

@@ -183,7 +183,7 @@ def test_split_k_reduction(model_repo, splitk, in_launch):
             os.environ.pop(k, None)
 
 
-@pytest.mark.parametrize("tile", range(6))
+@pytest.mark.parametrize("tile", range(8))
 @pytest.mark.parametrize("splitk", [1, 2])
 def test_raster_3x3_kernel(model_repo, tile, splitk):
     """LDS-window 3x3 kernel (nine shifted GEMMs over the padded raster): every tile shape, with and without split-K,
@@ -746,3 +746,52 @@ def test_unknown_precision_is_a_load_error(model_repo):
         with pytest.raises(RuntimeError, match="unsupported precision"):
             B.CreateModel(os.path.join(model_repo, "test_model", "1"), "test_model")
     _run_with_env(dict(IE_PRECISION="int3"), go)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ResNet (BASELINE.json configs[4] names ResNet-50): residual Add + ReLU, strided 1x1 / 3x3 convs, Conv->BN without ReLU, Gemm
+# classifier.  The reference holds no ResNet file or output, so this family is "parity unpinned" by the reference as well: the
+# checker is the float64 oracle on the same synthetic graph.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_resnet_mini_vs_float64_oracle(tmp_path, prec):
+    mb = models.resnet(3, layers=(2, 2, 2, 2), width=16, image=64, classes=20, seed=51)
+    path = models.write_repo(str(tmp_path), "resnet_mini", mb)
+    om = O.load_model(mb)
+    x = models.synthetic_input((3, 3, 64, 64), stream="resnet")
+    ref = O.run(om, {"data": x}, dtype=np.float64)["logits"]
+
+    def go():
+        m = B.CreateModel(path, "resnet_mini")
+        try:
+            return infer(m, "", "data", x, "logits", [3, 20])
+        finally:
+            m.Destroy()
+    y, dims = _run_with_env(dict(IE_PRECISION=prec), go)
+    assert dims == [3, 20]
+    e = rel_err(y, ref)
+    print(f"resnet mini {prec}: rel err vs float64 oracle {e:.2e}")
+    assert e < (RTOL if prec == "fp32" else F16_RTOL)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_resnet50_b2_vs_float64_oracle(tmp_path, prec):
+    """The full 53-conv ResNet-50 graph at 224x224, batch 2, against the float64 oracle (same seeded weights and inputs)."""
+    mb = models.resnet50("N")
+    path = models.write_repo(str(tmp_path), "resnet50", mb)
+    om = O.load_model(mb)
+    x = models.synthetic_input((2, 3, 224, 224), stream="resnet50")
+    ref = O.run(om, {"data": x}, dtype=np.float64)["logits"]
+
+    def go():
+        m = B.CreateModel(path, "resnet50")
+        try:
+            return infer(m, "", "data", x, "logits", [2, 1000])
+        finally:
+            m.Destroy()
+    y, dims = _run_with_env(dict(IE_PRECISION=prec), go)
+    assert dims == [2, 1000]
+    e = rel_err(y, ref)
+    print(f"resnet50 {prec} B=2: rel err vs float64 oracle {e:.2e}")
+    assert e < (RTOL if prec == "fp32" else 2e-2)
+    assert np.argmax(y, 1).tolist() == np.argmax(ref, 1).tolist()
