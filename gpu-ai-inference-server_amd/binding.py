@@ -248,9 +248,9 @@ class Model:
             cout = (CTensorData * max(len(outs), 1))()
             keep = []
             for i, t in enumerate(inputs):
-                if t.DataType != DataTypeFloat32:
+                if t.DataType not in (DataTypeFloat32, DataTypeUint8):
                     raise RuntimeError(f"unsupported data type for input '{t.Name}'")
-                arr = np.ascontiguousarray(t.Data, dtype=np.float32).ravel()
+                arr = np.ascontiguousarray(t.Data, dtype=np.float32 if t.DataType == DataTypeFloat32 else np.uint8).ravel()
                 nm = t.Name.encode()
                 keep.append(nm)
                 dims = list(t.Shape.Dims)
@@ -259,7 +259,7 @@ class Model:
                 buf = cmalloc(arr.nbytes)
                 C.memmove(buf, arr.ctypes.data, arr.nbytes)                      # copy #1 (:607-651)
                 cin[i].name = nm
-                cin[i].data_type = DataTypeFloat32
+                cin[i].data_type = t.DataType
                 cin[i].shape.dims = C.cast(dp, C.POINTER(C.c_int64))
                 cin[i].shape.num_dims = len(dims)
                 cin[i].data = buf

@@ -79,6 +79,7 @@ struct ModelObj {
     struct Pending {
         std::vector<const void*> in_ptr;
         std::vector<size_t> in_bytes;
+        std::vector<char> in_u8;          // 1 = UINT8 payload for a FLOAT32 graph input (converted on the device)
         std::vector<std::vector<int64_t>> shapes;
         TensorData* outputs = nullptr;
         int num_outputs = 0;
@@ -152,6 +153,20 @@ bool ModelObj::Load() {
                     }
                 }
                 auto dm = std::make_unique<ie::DeviceModel>(parsed, device_id, prec);
+                {   // UINT8 ingest transform x * scale + bias: config.json "uint8_scale" / "uint8_bias" (default 1/255, 0: the reference
+                    // client's /255 convention, client/test_client.py:189)
+                    std::ifstream cf(path + "/config.json");
+                    if (cf) {
+                        std::stringstream ss; ss << cf.rdbuf();
+                        const std::string txt = ss.str();
+                        std::smatch mm;
+                        float sc = 1.0f / 255.0f, bi = 0.0f;
+                        const std::string num = "(-?[0-9]*\\.?[0-9]+(?:[eE][-+]?[0-9]+)?)";
+                        if (std::regex_search(txt, mm, std::regex("\"uint8_scale\"\\s*:\\s*" + num))) sc = std::stof(mm[1]);
+                        if (std::regex_search(txt, mm, std::regex("\"uint8_bias\"\\s*:\\s*" + num))) bi = std::stof(mm[1]);
+                        dm->SetU8Transform(sc, bi);
+                    }
+                }
                 // Plan once at load (symbolic dims -> 1): rejects unsupported graphs here, like Ort::Session's
                 // constructor does, and puts the packed weights into HBM.
                 std::vector<std::vector<int64_t>> shapes;
@@ -414,6 +429,7 @@ bool ModelInfer(ModelHandle handle, const TensorData* inputs, int num_inputs, Te
             // ---- InferONNX (model.cpp:1158-1328): order inputs by graph index ----
             req.in_ptr.assign(gin.size(), nullptr);
             req.in_bytes.assign(gin.size(), 0);
+            req.in_u8.assign(gin.size(), 0);
             req.shapes.assign(gin.size(), {});
             req.outputs = outputs;
             req.num_outputs = num_outputs;
@@ -423,7 +439,9 @@ bool ModelInfer(ModelHandle handle, const TensorData* inputs, int num_inputs, Te
                 const std::string nm = t.name ? t.name : "";
                 for (size_t k = 0; k < gin.size(); ++k) {
                     if (gin[k].name != nm) continue;
-                    if (t.data_type != DATATYPE_FLOAT32) { req.err = "Unsupported data type for input: " + nm; break; }
+                    // FLOAT32 as in the reference (bridge:744), plus UINT8 image bytes that the engine converts on the device
+                    if (t.data_type != DATATYPE_FLOAT32 && t.data_type != DATATYPE_UINT8) { req.err = "Unsupported data type for input: " + nm; break; }
+                    req.in_u8[k] = t.data_type == DATATYPE_UINT8 ? 1 : 0;
                     provided[k] = 1;
                     req.shapes[k].clear();
                     if (t.shape.dims && t.shape.num_dims > 0) req.shapes[k].assign(t.shape.dims, t.shape.dims + t.shape.num_dims);
@@ -440,6 +458,7 @@ bool ModelInfer(ModelHandle handle, const TensorData* inputs, int num_inputs, Te
                 for (size_t k = 0; k < gin.size(); ++k)
                     if (req.shapes[k].size() != gin[k].dims.size() || req.shapes[k][0] != req.rows) batched = false;
                 if (req.rows <= 0 || req.rows >= M.max_batch) batched = false;
+                for (char u : req.in_u8) if (u) batched = false;          // byte payloads are not coalesced
             }
             if (!batched) req.rows = 0;     // rows > 0 marks a request that may be padded / coalesced
         }
@@ -497,7 +516,7 @@ void ModelObj::Execute(std::vector<Pending*>& batch) {
                 out_ptr.push_back(copy ? r.outputs[i].data : nullptr);
                 out_bytes.push_back(copy ? r.outputs[i].data_size : 0);
             }
-            dev->InferHost(pi, r.in_ptr, r.in_bytes, out_ptr, out_bytes);
+            dev->InferHost(pi, r.in_ptr, r.in_bytes, out_ptr, out_bytes, r.in_u8);
             write_out_dims(r.outputs, r.num_outputs, pi.plan.outputs, 0);
             r.ok = true;
             return;

@@ -186,6 +186,7 @@ void DeviceModel::FreeInstance(PlanInstance& pi) {
         if (pi.buffers[i] && pi.owned[i]) (void)hipFree(pi.buffers[i]);
     if (pi.workspace) (void)hipFree(pi.workspace);
     if (pi.counters) (void)hipFree(pi.counters);
+    for (void* p : pi.u8_stage) if (p) (void)hipFree(p);
     if (pi.done) (void)hipEventDestroy(pi.done);
     if (pi.fork) (void)hipEventDestroy(pi.fork);
 }
@@ -657,11 +658,12 @@ std::vector<StepTiming> DeviceModel::Profile(PlanInstance& pi, int iters) {
 }
 
 void DeviceModel::InferHost(PlanInstance& pi, const std::vector<const void*>& inputs, const std::vector<size_t>& in_bytes,
-                            const std::vector<void*>& outputs, const std::vector<size_t>& out_bytes) {
+                            const std::vector<void*>& outputs, const std::vector<size_t>& out_bytes, const std::vector<char>& in_u8) {
     std::vector<std::vector<InSeg>> in(pi.plan.inputs.size());
     for (size_t i = 0; i < pi.plan.inputs.size(); ++i) {
-        const size_t need = size_t(pi.plan.inputs[i].view.numel()) * sizeof(float);
-        in[i].push_back({inputs[i], inputs[i] ? std::min(in_bytes[i], need) : 0, need, 0});
+        const bool u8 = i < in_u8.size() && in_u8[i];
+        const size_t need = size_t(pi.plan.inputs[i].view.numel()) * (u8 ? 1 : sizeof(float));
+        in[i].push_back({inputs[i], inputs[i] ? std::min(in_bytes[i], need) : 0, need, 0, u8});
     }
     std::vector<std::vector<OutSeg>> out(pi.plan.outputs.size());
     for (size_t i = 0; i < outputs.size() && i < pi.plan.outputs.size(); ++i) {
@@ -683,7 +685,17 @@ void DeviceModel::InferHostSegments(PlanInstance& pi, const std::vector<std::vec
         for (size_t i = 0; i < pi.plan.inputs.size() && i < in.size(); ++i) {
             const View& v = pi.plan.inputs[i].view;
             char* base = reinterpret_cast<char*>(pi.buffers[size_t(v.buf)]);
+            const bool u8 = !in[i].empty() && in[i][0].u8;
+            if (u8) {       // bytes go to a device staging buffer; one kernel converts them into the fp32 input buffer afterwards
+                if (pi.u8_stage.size() < pi.plan.inputs.size()) pi.u8_stage.resize(pi.plan.inputs.size(), nullptr);
+                if (!pi.u8_stage[i]) {
+                    check(hipMalloc(&pi.u8_stage[i], std::max<size_t>(size_t(v.numel()), 16)), "hipMalloc(u8 staging)");
+                    device_bytes_ += size_t(v.numel());
+                }
+                base = static_cast<char*>(pi.u8_stage[i]);
+            }
             for (const InSeg& sg : in[i]) {
+                if (sg.u8 != u8) throw std::runtime_error("internal error: mixed UINT8 / FLOAT32 segments for one input");
                 char* dst = base + sg.dev_off;
                 const size_t have = sg.host ? std::min(sg.have, sg.need) : 0;
                 for (size_t off = 0; off < have; off += kChunk) {
@@ -698,6 +710,8 @@ void DeviceModel::InferHostSegments(PlanInstance& pi, const std::vector<std::vec
                 }
                 if (have < sg.need) check(hipMemsetAsync(dst + have, 0, sg.need - have, stream_), "hipMemsetAsync");
             }
+            if (u8)
+                check(LaunchConvertU8ToF32(pi.u8_stage[i], pi.buffers[size_t(v.buf)], v.numel(), u8_scale_, u8_bias_, stream_), "convert_u8_f32");
         }
         Enqueue(pi);
         // ---- D2H: one transfer per output when it fits the ring, then per-caller scatter on the host ----------

@@ -42,6 +42,7 @@ struct PlanInstance {
     int* counters = nullptr;           // split-K arrival counters (zero between launches)
     hipGraphExec_t graph_exec = nullptr;
     bool graph_ready = false;
+    std::vector<void*> u8_stage;       // per graph input: device staging for UINT8 payloads (allocated on first use)
 };
 
 // A few helper threads that split big host memcpys (caller buffer -> pinned staging).  One thread moves ~10 GB/s, the
@@ -83,12 +84,15 @@ public:
     // Host-buffer inference (the ModelInfer path): inputs[i] has in_bytes[i] valid bytes (shorter payloads are
     // zero-extended like the reference's zero-initialised Tensor), outputs[i] receives min(out_bytes[i], produced)
     // bytes and the rest of the caller buffer is zero-filled.
+    // in_u8[i] != 0: inputs[i] is a UINT8 payload (one byte per element); it is uploaded as bytes and converted on the device
+    // (x * u8_scale + u8_bias), cutting the PCIe traffic of an image batch 4x.
     void InferHost(PlanInstance& pi, const std::vector<const void*>& inputs, const std::vector<size_t>& in_bytes,
-                   const std::vector<void*>& outputs, const std::vector<size_t>& out_bytes);
+                   const std::vector<void*>& outputs, const std::vector<size_t>& out_bytes, const std::vector<char>& in_u8 = {});
+    void SetU8Transform(float scale, float bias) { u8_scale_ = scale; u8_bias_ = bias; }
     // Gather/scatter form used by the dynamic batcher: several callers' row blocks land at byte offsets of one device batch.
     // Input segment: `have` valid bytes at `host`, zero-extended to `need` bytes, placed at `dev_off` of input k.
     // Output segment: min(cap, need) bytes from `dev_off` of output j copied to `host`, the rest of `cap` zero-filled.
-    struct InSeg { const void* host; size_t have, need, dev_off; };
+    struct InSeg { const void* host; size_t have, need, dev_off; bool u8 = false; };   // u8: have/need/dev_off count bytes = elements
     struct OutSeg { void* host; size_t cap, need, dev_off; };
     void InferHostSegments(PlanInstance& pi, const std::vector<std::vector<InSeg>>& in, const std::vector<std::vector<OutSeg>>& out);
 
@@ -121,6 +125,7 @@ private:
     Precision precision_ = Precision::F32;
     size_t weight_floats_ = 0;
     size_t device_bytes_ = 0;
+    float u8_scale_ = 1.0f / 255.0f, u8_bias_ = 0.0f;
     bool use_graph_ = true;
     bool autotune_ = true;
     int sub_streams_ = 1;              // IE_STREAMS: sub-batches run concurrently per forward

@@ -97,6 +97,8 @@ bool ConvStemEligible(const ConvArgs& a);
 hipError_t LaunchConvStem(const ConvArgs& a, hipStream_t stream);
 hipError_t InitKernelsStem();
 hipError_t LaunchConvertF32ToF16(const float* src, void* dst, int64_t n, hipStream_t stream);
+// UINT8 ingest: dst[i] = float(src[i]) * scale + bias (images travel over PCIe as bytes, 4x fewer than fp32)
+hipError_t LaunchConvertU8ToF32(const void* src, float* dst, int64_t n, float scale, float bias, hipStream_t stream);
 hipError_t LaunchPool(const PoolArgs& a, hipStream_t stream);
 // out[n, c] = mean over (y, x) of f(in[n, y, x, c]),  f = optional scale/shift/ReLU prologue
 hipError_t LaunchGlobalAvgPool(const TensorArg& in, const TensorArg& out, const float* pre_scale, const float* pre_shift,

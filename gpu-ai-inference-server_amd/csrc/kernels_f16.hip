@@ -346,4 +346,34 @@ hipError_t LaunchConvertF32ToF16(const float* src, void* dst, int64_t n, hipStre
     return hipGetLastError();
 }
 
+__global__ void convert_u8_f32_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst, const int64_t n, const float scale,
+                                      const float bias) {
+#pragma clang fp contract(off)      // keep x * scale + bias as two rounded operations: bit-identical to the host-side expression
+    // 16 source bytes per lane when aligned, scalar tail otherwise
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    const int64_t nv = ((reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) ? n / 16 : 0;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < nv; i += stride) {
+        const uint4 v = reinterpret_cast<const uint4*>(src)[i];
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float4 o;
+            o.x = float(w[k] & 0xffu) * scale + bias;
+            o.y = float((w[k] >> 8) & 0xffu) * scale + bias;
+            o.z = float((w[k] >> 16) & 0xffu) * scale + bias;
+            o.w = float(w[k] >> 24) * scale + bias;
+            reinterpret_cast<float4*>(dst)[i * 4 + k] = o;
+        }
+    }
+    for (int64_t i = nv * 16 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = float(src[i]) * scale + bias;
+}
+
+hipError_t LaunchConvertU8ToF32(const void* src, float* dst, int64_t n, float scale, float bias, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    const int64_t work = (n + 15) / 16;
+    const int64_t blocks = (work + 255) / 256 < 8192 ? (work + 255) / 256 : 8192;
+    convert_u8_f32_kernel<<<dim3(unsigned(blocks)), dim3(256), 0, stream>>>(static_cast<const unsigned char*>(src), dst, n, scale, bias);
+    return hipGetLastError();
+}
+
 }  // namespace ie

@@ -795,3 +795,38 @@ def test_resnet50_b2_vs_float64_oracle(tmp_path, prec):
     print(f"resnet50 {prec} B=2: rel err vs float64 oracle {e:.2e}")
     assert e < (RTOL if prec == "fp32" else 2e-2)
     assert np.argmax(y, 1).tolist() == np.argmax(ref, 1).tolist()
+
+
+def test_uint8_ingest_matches_float_path(densenet_repo, tmp_path):
+    """a FLOAT32 graph input may be fed as UINT8 bytes (DATATYPE_UINT8 exists in the reference ABI,
+    inference_bridge.h:25, but its ModelInfer rejects everything except FLOAT32); the engine uploads the bytes (4x fewer over
+    PCIe) and converts on the device with x * uint8_scale + uint8_bias (config.json; default 1/255, 0).  The result must be
+    bit-identical to feeding the same converted floats."""
+    import shutil
+    rs = np.random.RandomState(7)
+    xb = rs.randint(0, 256, size=(5, 3, 224, 224)).astype(np.uint8)
+    for scale, bias, cfg_extra in ((np.float32(1.0) / np.float32(255.0), np.float32(0.0), ""),
+                                   (np.float32(0.017), np.float32(-1.5), ',"uint8_scale":0.017,"uint8_bias":-1.5')):
+        root = str(tmp_path / f"repo{len(cfg_extra)}")
+        shutil.copytree(densenet_repo, root)
+        cfg_path = os.path.join(root, "densenet_onnx", "1", "config.json")
+        with open(cfg_path) as f:
+            cfg = f.read()
+        with open(cfg_path, "w") as f:
+            f.write(cfg[:-1] + cfg_extra + "}")
+        m = B.CreateModel(os.path.join(root, "densenet_onnx", "1"), "densenet_onnx")
+        try:
+            xf = xb.astype(np.float32) * scale + bias
+            outs = [B.OutputConfig("fc6_1", Shape=[5, 1000, 1, 1], DataType="FLOAT32")]
+            yf = m.Infer([B.TensorData("data_0", B.DataTypeFloat32, B.Shape([5, 3, 224, 224]), xf)], outs)[0].Data.copy()
+            yu = m.Infer([B.TensorData("data_0", B.DataTypeUint8, B.Shape([5, 3, 224, 224]), xb)], outs)[0].Data.copy()
+            assert np.isfinite(yu).all()
+            np.testing.assert_array_equal(yu, yf)
+            # a short payload is zero-extended like the reference's zero-initialised Tensor (bytes 0 -> bias)
+            yshort = m.Infer([B.TensorData("data_0", B.DataTypeUint8, B.Shape([5, 3, 224, 224]), xb.reshape(-1)[:3 * 224 * 224 * 2])], outs)[0].Data
+            xpad = np.zeros_like(xb)
+            xpad.reshape(-1)[:3 * 224 * 224 * 2] = xb.reshape(-1)[:3 * 224 * 224 * 2]
+            yref = m.Infer([B.TensorData("data_0", B.DataTypeFloat32, B.Shape([5, 3, 224, 224]), xpad.astype(np.float32) * scale + bias)], outs)[0].Data
+            np.testing.assert_array_equal(yshort, yref)
+        finally:
+            m.Destroy()
