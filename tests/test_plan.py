@@ -89,3 +89,59 @@ def test_packed_and_unpacked_attribute_encodings(tmp_path):
         f.write_bytes(pb.model(g))
         s = B.DescribeModel(str(f), 1)["plan"]["steps"][0]
         assert (s["k"], s["stride"], s["pads"], s["out"]["h"], s["out"]["w"]) == ([3, 3], [2, 2], [1, 1, 1, 1], 4, 4)
+
+
+def test_fp16_plan_keeps_graph_io_fp32(densenet_repo, monkeypatch):
+    """fp16 precision mode: every buffer between the graph's fp32 input and fp32 output holds halfs; bytes per image halve."""
+    monkeypatch.setenv("IE_PRECISION", "fp16")
+    p = B.DescribeModel(os.path.join(densenet_repo, "densenet_onnx", "1"), 32)["plan"]
+    assert p["precision"] == "fp16"
+    assert not p["inputs"][0]["view"]["f16"] and not p["outputs"][0]["view"]["f16"]
+    convs = [s for s in p["steps"] if s["kind"] == "conv"]
+    assert convs[0]["algo"] == "stem" and not convs[0]["in"]["f16"] and convs[0]["out"]["f16"]      # fp32 NCHW in, half NHWC out
+    assert all(s["in"]["f16"] and s["out"]["f16"] for s in convs[1:-1])
+    assert convs[-1]["in"]["f16"] and not convs[-1]["out"]["f16"]                                    # classifier writes fp32 logits
+    assert 47e6 < sum(s["bytes"] for s in p["steps"]) / 32 < 50e6                                    # SURVEY §8d: 47.6 MB/img + weights/32
+    assert p["activation_bytes"] < 170e6                                                             # vs 300 MB in fp32
+    monkeypatch.setenv("IE_PRECISION", "fp32")
+    p32 = B.DescribeModel(os.path.join(densenet_repo, "densenet_onnx", "1"), 32)["plan"]
+    assert p32["precision"] == "fp32" and not any(s["in"]["f16"] or s["out"]["f16"] for s in p32["steps"])
+
+
+def test_forced_algorithms_respect_eligibility(densenet_repo, monkeypatch):
+    """IE_FORCE_ALGO only switches convs that the target kernel can run (the rest keep the implicit GEMM)."""
+    path = os.path.join(densenet_repo, "densenet_onnx", "1")
+    monkeypatch.setenv("IE_FORCE_ALGO", "ws")
+    monkeypatch.setenv("IE_FORCE_TILE", "4")          # 32 output channels per workgroup: every K up to 1024 fits in LDS
+    p = B.DescribeModel(path, 32)["plan"]
+    ws = [s for s in p["steps"] if s.get("algo") == "ws1x1"]
+    assert len(ws) >= 58 and all(s["k"] == [1, 1] and s["stride"] == [1, 1] for s in ws)
+    assert all(s["algo"] != "ws3x3" for s in p["steps"] if s["kind"] == "conv")                       # fp32: no resident-weight 3x3
+    monkeypatch.setenv("IE_PRECISION", "fp16")
+    p = B.DescribeModel(path, 32)["plan"]
+    assert sum(1 for s in p["steps"] if s.get("algo") == "ws3x3") == 58                                # every growth conv
+    monkeypatch.setenv("IE_FORCE_ALGO", "direct")
+    monkeypatch.setenv("IE_FORCE_TILE", "0")          # 8 waves x up to 8 chunks
+    monkeypatch.setenv("IE_PRECISION", "fp32")
+    p = B.DescribeModel(path, 32)["plan"]
+    d = [s for s in p["steps"] if s.get("algo") == "direct"]
+    assert d and all(8 <= s["k"][0] * s["k"][1] * s["in"]["c"] // 16 <= 64 and s["out"]["n"] * s["out"]["h"] * s["out"]["w"] <= 65536 for s in d)
+
+
+def test_resnet50_plan_fuses_shortcuts(tmp_path):
+    """ResNet-50: 53 convs + Gemm, every BN folded, all 16 residual Add+ReLU pairs folded into a conv epilogue (the shortcut that
+    already exists when the conv runs becomes its `in2`), 8.2 GFLOP per image."""
+    path = models.write_repo(str(tmp_path), "resnet50", models.resnet50("N"))
+    d = B.DescribeModel(path, 32)
+    assert d["inputs"][0]["dims"] == [-1, 3, 224, 224] and d["outputs"][0]["dims"] == [-1, 1000]
+    p = d["plan"]
+    kinds = [s["kind"] for s in p["steps"]]
+    assert kinds.count("conv") == 54 and kinds.count("eltwise") == 0 and kinds.count("pool") == 1 and kinds.count("gap") == 1
+    res = [s for s in p["steps"] if s["kind"] == "conv" and s["residual"]]
+    assert len(res) == 16 and all(s["relu"] and s["k"] == [1, 1] for s in res)
+    for s in res:       # the shortcut has the output's shape and lives in another buffer
+        assert (s["in2"]["n"], s["in2"]["c"], s["in2"]["h"], s["in2"]["w"]) == (s["out"]["n"], s["out"]["c"], s["out"]["h"], s["out"]["w"])
+        assert s["in2"]["buf"] != s["out"]["buf"]
+    # projection blocks: the Add rides on the projection conv (its partner branch is complete by then), 4 of them strided or not
+    assert sum(1 for s in res if "proj" in s["name"]) == 4
+    assert abs(p["total_flops"] / 32 / 8.18e9 - 1) < 1e-2
