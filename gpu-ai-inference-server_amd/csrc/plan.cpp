@@ -729,7 +729,9 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                                       s.in.n * s.in.h * s.in.w * s.in.pitch * 2 < (int64_t(1) << 31) && int64_t(n.w.size()) * 2 < (int64_t(1) << 31) &&
                                       s.out.n * s.out.h * s.out.w * s.out.pitch < (int64_t(1) << 31);
                 const int64_t bk = in16 ? 2 * kIgemmBK : kIgemmBK;       // K-tile depth in elements (128 B per LDS row either way)
-                if (M * N < 2048 && K <= 4096) s.algo = ConvAlgo::Naive;
+                // one-thread-per-output only for toy problems (test_model's 3->5->2 MLP): at batch 1 DenseNet's block-4 convs have
+                // M*N = 1568 outputs but K = 1152 - the naive kernel took 141 us there, the MFMA kernels 13 us
+                if (M * N * K <= 32768 || (M * N < 2048 && K <= 4096 && !(vec_ok || vec16_ok))) s.algo = ConvAlgo::Naive;
                 else if (vec_ok || vec16_ok) s.algo = ConvAlgo::IgemmVec;
                 else if (K <= 2048 && !in16) s.algo = ConvAlgo::IgemmScalar;
                 else s.algo = ConvAlgo::Naive;
