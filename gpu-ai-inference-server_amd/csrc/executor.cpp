@@ -147,7 +147,7 @@ DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id, 
             std::string tok;
             while (is >> tok && tok != ":") key.push_back(std::stoll(tok));
             int t = -1, sp = 0;
-            if ((is >> t >> sp) && ((t >= 0 && t < kNumIgemmTiles) || (t >= 100 && t < 100 + kNumConvRasterTiles) || (t >= 200 && t < 200 + kNumConvWsTiles) ||
+            if ((is >> t >> sp) && ((t >= 0 && t < kNumIgemmTiles) || (t >= 100 && t < 100 + kNumConvRasterTiles) || (t >= 200 && t < 200 + kNumConvWs32Tiles) ||
                                      (t >= 300 && t < 300 + kNumConvWs3Tiles) || (t >= 400 && t < 400 + kNumConvDirectTiles)) &&
                 sp >= 1 && sp <= 64)
                 tune_cache_[key] = {t, sp};
@@ -414,7 +414,7 @@ void DeviceModel::Autotune(PlanInstance& pi) {
             // 1x1/s1: weights-stationary streaming kernel (either precision)
             if (s.algo == ConvAlgo::IgemmVec && s.kh == 1 && s.kw == 1) {
                 ConvArgs probe = MakeConvArgs(pi, s);
-                for (int t = 0; t < kNumConvWsTiles; ++t) {
+                for (int t = 0; t < (s.in.f16 ? kNumConvWsTiles : kNumConvWs32Tiles); ++t) {
                     if (!(s.in.f16 ? ConvWsEligible(probe, t) : ConvWs32Eligible(probe, t))) continue;
                     Step trial = s;
                     trial.algo = ConvAlgo::Ws1x1;

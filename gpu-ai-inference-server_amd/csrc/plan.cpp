@@ -754,8 +754,8 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                         s.algo = (vec_ok || vec16_ok) ? ConvAlgo::IgemmVec : (K <= 2048 && !in16 ? ConvAlgo::IgemmScalar : ConvAlgo::Naive);
                     else if (f == "ws") {
                         int t = 0;
-                        if (const char* ft = std::getenv("IE_FORCE_TILE")) { int v = std::atoi(ft); if (v >= 0 && v < 12) t = v; }
-                        static const int ws_tn[12] = {4, 4, 2, 2, 1, 1, 4, 4, 2, 2, 1, 1};
+                        if (const char* ft = std::getenv("IE_FORCE_TILE")) { int v = std::atoi(ft); if (v >= 0 && v < (in16 ? 12 : 14)) t = v; }
+                        static const int ws_tn[14] = {4, 4, 2, 2, 1, 1, 4, 4, 2, 2, 1, 1, 1, 1};      // 12, 13: fp32 K-split variants (8 / 4 waves)
                         const bool eligible = vec16_ok && n.kh == 1 && n.kw == 1 && n.sh == 1 && n.sw == 1 && n.pt == 0 && n.pl == 0 && n.pb == 0 &&
                                               n.pr == 0 && s.in.c % 32 == 0 && (32 * ws_tn[t] * (s.in.c + 8) + 2 * s.in.c) * 2 + 128 * ws_tn[t] <= 160 * 1024 &&
                                               !(ws_tn[t] > 1 && N <= 32 * (ws_tn[t] / 2));
@@ -767,7 +767,10 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                                                pr3 <= ws3_cfg[t3][2] * (64 * ws3_cfg[t3][0] / 8) &&
                                                (9 * ((s.in.c + 63) / 64) * 32 + pr3) * 144 + 128 <= 160 * 1024;
                         const bool eligible32 = vec_ok && !s.out.f16 && n.kh == 1 && n.kw == 1 && n.sh == 1 && n.sw == 1 && n.pt == 0 && n.pl == 0 &&
-                                                n.pb == 0 && n.pr == 0 && s.in.c % 16 == 0 && (32 * ws_tn[t] * (s.in.c + 4) + 2 * s.in.c + 32 * ws_tn[t]) * 4 <= 160 * 1024 &&
+                                                n.pb == 0 && n.pr == 0 && s.in.c % 16 == 0 &&
+                                                (t < 12 ? (32 * ws_tn[t] * (s.in.c + 4) + 2 * s.in.c + 32 * ws_tn[t]) * 4 <= 160 * 1024
+                                                        : (s.in.c / 16 >= (t == 12 ? 8 : 4) &&
+                                                           (32 * (s.in.c + 4) + 2 * s.in.c + 32 + (t == 12 ? 4 : 2) * 32 * 36) * 4 <= 160 * 1024)) &&
                                                 !(ws_tn[t] > 1 && N <= 32 * (ws_tn[t] / 2)) && N % 4 == 0 && s.out.pitch % 4 == 0 && s.out.c_off % 4 == 0;
                         if (eligible || eligible32) { s.algo = ConvAlgo::Ws1x1; s.tile = t; }
                         else if (eligible3) { s.algo = ConvAlgo::Ws3x3; s.tile = t3; }
