@@ -533,6 +533,7 @@ void DeviceModel::LaunchStep(const PlanInstance& pi, const Step& s, hipStream_t 
             a.out = make_arg(pi, s.out);
             a.kh = s.kh; a.kw = s.kw; a.sh = s.sh; a.sw = s.sw; a.pt = s.pt; a.pl = s.pl; a.pb = s.pb; a.pr = s.pr;
             a.is_max = s.pool_max; a.count_include_pad = s.count_include_pad;
+            a.pre_scale = wp(s.pre_scale_off); a.pre_shift = wp(s.pre_shift_off); a.pre_relu = s.pre_relu;
             check(LaunchPool(a, stream_), "pool");
             break;
         }

@@ -42,6 +42,9 @@ struct PoolArgs {
     TensorArg in, out;                 // NHWC
     int kh = 1, kw = 1, sh = 1, sw = 1, pt = 0, pl = 0, pb = 0, pr = 0;
     int is_max = 0, count_include_pad = 0;
+    const float* pre_scale = nullptr;  // per channel: x <- x*scale + shift (then ReLU if pre_relu) before pooling
+    const float* pre_shift = nullptr;  // (a transition's BN -> ReLU -> 1x1 conv -> AvgPool runs as BN -> ReLU -> AvgPool -> 1x1 conv)
+    int pre_relu = 0;
 };
 
 struct EltArgs {

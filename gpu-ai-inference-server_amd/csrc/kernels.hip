@@ -1097,9 +1097,13 @@ __global__ void pool_kernel(const PoolArgs a, const int64_t total) {
     const int ox = int(m % a.out.w); m /= a.out.w;
     const int oy = int(m % a.out.h);
     const int b = int(m / a.out.h);
-    float acc[V];
+    float acc[V], ps[V], pt[V];
 #pragma unroll
-    for (int v = 0; v < V; ++v) acc[v] = a.is_max ? -INFINITY : 0.f;
+    for (int v = 0; v < V; ++v) {
+        acc[v] = a.is_max ? -INFINITY : 0.f;
+        ps[v] = a.pre_scale ? a.pre_scale[c + v] : 1.f;
+        pt[v] = a.pre_scale ? a.pre_shift[c + v] : 0.f;
+    }
     int cnt = 0;
     for (int ky = 0; ky < a.kh; ++ky) {
         const int iy = oy * a.sh - a.pt + ky;
@@ -1120,6 +1124,13 @@ __global__ void pool_kernel(const PoolArgs a, const int64_t total) {
 #pragma unroll
                 for (int v = 0; v < 8; ++v) x[v] = float(t[v]);
             } else x[0] = ld_elem(a.in.p, a.in.f16, off);
+            if (a.pre_scale) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const float y = x[v] * ps[v] + pt[v];
+                    x[v] = a.pre_relu ? fmaxf(y, 0.f) : y;
+                }
+            }
 #pragma unroll
             for (int v = 0; v < V; ++v) acc[v] = a.is_max ? fmaxf(acc[v], x[v]) : acc[v] + x[v];
         }

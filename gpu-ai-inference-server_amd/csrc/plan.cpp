@@ -464,10 +464,45 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
             b.dead = true;
         }
     }
-    // ---- fusion 3: prologues (Affine -> Relu -> {Conv, GlobalAveragePool}) -------------------------
+    // ---- fusion 2c: Conv1x1 -> AveragePool  ==>  AveragePool -> Conv1x1 ---------------------------------
+    // Both are linear and a 1x1/stride-1 conv acts per pixel, so they commute (the conv's bias too: the mean of a constant is the
+    // constant).  DenseNet's transitions (BN -> ReLU -> Conv1x1 -> AvgPool2x2) then run their conv on a quarter of the pixels:
+    // 4x fewer FLOPs for those layers (8 % of the network), and the BN+ReLU prologue rides on the pool.  Only when the pool window
+    // tiles the image exactly (no padding, no partial windows), so every output averages the same number of inputs.
+    if (!std::getenv("IE_NO_POOL_SWAP")) {
+        for (size_t i = 0; i < L.nodes.size(); ++i) {
+            if (L.nodes[i].dead || L.nodes[i].kind != L_CONV) continue;
+            const LNode& cv0 = L.nodes[i];
+            if (cv0.kh != 1 || cv0.kw != 1 || cv0.sh != 1 || cv0.sw != 1 || cv0.pt || cv0.pl || cv0.pb || cv0.pr || cv0.relu || cv0.res >= 0) continue;
+            if (!single_consumer(cv0.out)) continue;
+            const int pj = L.consumers(cv0.out)[0];
+            const LNode& pl0 = L.nodes[pj];
+            const Val& X = L.vals[cv0.in[0]];
+            if (pl0.kind != L_AVGPOOL || pl0.pt || pl0.pl || pl0.pb || pl0.pr || pl0.kh != pl0.sh || pl0.kw != pl0.sw || X.h % pl0.kh || X.w % pl0.kw ||
+                X.is_input)
+                continue;
+            // new value: the pooled conv input [N, Cin, H/k, W/k]
+            const int x = cv0.in[0], conv_out = cv0.out, pool_out = pl0.out;
+            const int pooled = L.new_val(L.vals[x].name + "/pooled@" + pl0.name, {X.n, X.c, X.h / pl0.kh, X.w / pl0.kw});
+            LNode conv = L.nodes[i], pool = L.nodes[size_t(pj)];
+            pool.in = {x};
+            pool.out = pooled;
+            pool.name = pl0.name + "(before " + cv0.name + ")";
+            conv.in[0] = pooled;
+            conv.out = pool_out;                        // same dims as before: [N, Cout, H/k, W/k]
+            (void)conv_out;                             // the full-resolution conv output no longer exists
+            // the pool takes the conv's slot in the schedule, the conv the pool's (everything in between is independent of both)
+            L.nodes[i] = pool;
+            L.nodes[size_t(pj)] = conv;
+            L.vals[pooled].producer = int(i);
+            L.vals[pool_out].producer = pj;
+            L.vals[conv_out].producer = -1;
+        }
+    }
+    // ---- fusion 3: prologues (Affine -> Relu -> {Conv, GlobalAveragePool, swapped AveragePool}) ---------
     for (size_t i = 0; i < L.nodes.size(); ++i) {
         LNode& cv = L.nodes[i];
-        if (cv.dead || (cv.kind != L_CONV && cv.kind != L_GAP)) continue;
+        if (cv.dead || (cv.kind != L_CONV && cv.kind != L_GAP && cv.kind != L_AVGPOOL)) continue;
         int x = cv.in[0];
         bool took_relu = false;
         int p = L.vals[x].producer;

@@ -209,6 +209,31 @@ def test_raster_3x3_kernel(model_repo, tile, splitk):
             os.environ.pop(k, None)
 
 
+def test_pool_conv_swap_matches_unswapped_graph(model_repo):
+    """Transitions run AvgPool before their 1x1 conv (linear ops commute; 4x fewer conv FLOPs).  Same logits as the graph order up
+    to fp32 summation order, and both within the contract of the float64 fixture."""
+    name = "mini_densenet_scale"
+    mk, iname, ishape = MINI[name]
+    x = models.synthetic_input(ishape, stream=name)
+    ref64 = np.load(os.path.join(GOLD, name + ".npz"))["output_f64"]
+    ys = []
+    for env in (dict(), dict(IE_NO_POOL_SWAP="1")):
+        os.environ.update(env)
+        try:
+            d = B.DescribeModel(os.path.join(model_repo, name, "1"), ishape[0])
+            assert any(s["kind"] == "pool" and s["pre"] for s in d["plan"]["steps"]) == (not env)
+            m = B.CreateModel(os.path.join(model_repo, name, "1"), name)
+            try:
+                ys.append(infer(m, "", iname, x, "fc6_1", [3, 17, 1, 1])[0])
+            finally:
+                m.Destroy()
+        finally:
+            for k_ in env:
+                os.environ.pop(k_, None)
+    assert rel_err(ys[0], ref64) < RTOL and rel_err(ys[1], ref64) < RTOL
+    assert rel_err(ys[0], ys[1]) < 2e-6
+
+
 def test_naive_kernel_agrees(model_repo):
     os.environ["IE_FORCE_ALGO"] = "naive"
     try:
