@@ -85,3 +85,15 @@ def test_oracle_vs_float64_fixture_densenet121():
     y = O.run(m, {"data_0": x})["fc6_1"].reshape(2, 1000)
     rel = np.abs(y - g["logits_f64"]).max() / np.abs(g["logits_f64"]).max()
     assert rel < 1e-4, rel
+
+
+def test_torch_cpu_walk_matches_numpy_oracle():
+    """bench.py's faster CPU baseline (the oracle's graph walk on torch-CPU primitives) computes the same function."""
+    pytest.importorskip("torch")
+    for mb, feeds in ((models.densenet(2, growth=8, blocks=(2, 3), stem=16, image=32, classes=10, seed=5), "data_0"),
+                      (models.resnet(2, layers=(1, 1, 1, 1), width=8, image=32, classes=7, seed=3), "data")):
+        m = O.load_model(mb)
+        x = models.synthetic_input((2, 3, 32, 32), stream="torchwalk")
+        a = list(O.run(m, {feeds: x}, dtype=np.float64).values())[0]
+        b = list(O.run_torch_cpu(m, {feeds: x}).values())[0]
+        assert np.abs(a - b).max() / np.abs(a).max() < 1e-5
