@@ -110,9 +110,9 @@ def cpu_baseline(sample_images: int, model: str = "densenet121", backend: str = 
         t0 = time.perf_counter()
         O.run(m, {iname: x})
         dt = time.perf_counter() - t0
-        how = f"numpy im2col + BLAS oracle, {dt:.1f} s"
+        how = f"numpy im2col + BLAS oracle, one forward, {dt:.1f} s"
     return {"value": round(sample_images / dt, 3), "unit": "images/sec", "cores": int(cores), "kind": "port",
-            "sample": f"{sample_images} images of the same synthetic {MODELS[model][3]} fp32 workload, one forward ({how}); "
+            "sample": f"batches of {sample_images} images of the same synthetic {MODELS[model][3]} fp32 workload ({how}); "
                       f"stand-in for the absent ONNX Runtime CPU EP"}
 
 
