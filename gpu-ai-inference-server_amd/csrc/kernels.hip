@@ -1101,8 +1101,22 @@ __global__ void pool_kernel(const PoolArgs a, const int64_t total) {
 #pragma unroll
     for (int v = 0; v < V; ++v) {
         acc[v] = a.is_max ? -INFINITY : 0.f;
-        ps[v] = a.pre_scale ? a.pre_scale[c + v] : 1.f;
-        pt[v] = a.pre_scale ? a.pre_shift[c + v] : 0.f;
+        ps[v] = 1.f;
+        pt[v] = 0.f;
+    }
+    if (a.pre_scale) {
+        if constexpr (V >= 4) {        // c is a multiple of V and the blob's sub-arrays are 32-byte aligned: 16-byte loads
+#pragma unroll
+            for (int q = 0; q < V / 4; ++q) {
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(a.pre_scale + c + 4 * q);
+                const f32x4 t4 = *reinterpret_cast<const f32x4*>(a.pre_shift + c + 4 * q);
+                ps[4 * q] = s4.x; ps[4 * q + 1] = s4.y; ps[4 * q + 2] = s4.z; ps[4 * q + 3] = s4.w;
+                pt[4 * q] = t4.x; pt[4 * q + 1] = t4.y; pt[4 * q + 2] = t4.z; pt[4 * q + 3] = t4.w;
+            }
+        } else {
+            ps[0] = a.pre_scale[c];
+            pt[0] = a.pre_shift[c];
+        }
     }
     int cnt = 0;
     for (int ky = 0; ky < a.kh; ++ky) {
