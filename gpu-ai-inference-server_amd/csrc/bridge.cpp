@@ -12,6 +12,7 @@
 //   * no CPU execution provider: without a HIP device Load fails loudly
 #include <atomic>
 #include <cctype>
+#include <dlfcn.h>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -44,6 +45,33 @@ static_assert(sizeof(ModelStats) == 32, "ModelStats layout");
 static_assert(sizeof(CudaMemoryInfo) == 24, "CudaMemoryInfo layout");
 
 namespace {
+
+// Optional ROCTX ranges: one range per ModelInfer call, named after the model, when IE_ROCTX=1 and the ROCm
+// marker library is present (`rocprofv3 --marker-trace` then shows requests next to the kernels).  Loaded lazily with dlopen so
+// the engine keeps libamdhip64 as its only link-time dependency.
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char* e = std::getenv("IE_ROCTX");
+        if (!e || e[0] != '1') return;
+        for (const char* name : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+            if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+                push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+                pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (push && pop) return;
+                push = nullptr; pop = nullptr;
+            }
+        }
+    }
+};
+const Roctx& roctx() { static Roctx r; return r; }
+struct RoctxRange {
+    bool on;
+    explicit RoctxRange(const std::string& name) : on(roctx().push != nullptr) { if (on) roctx().push(name.c_str()); }
+    ~RoctxRange() { if (on) roctx().pop(); }
+};
+
 
 char* dup_cstr(const std::string& s) {
     char* p = static_cast<char*>(std::malloc(s.size() + 1));
@@ -464,6 +492,7 @@ bool ModelInfer(ModelHandle handle, const TensorData* inputs, int num_inputs, Te
         }
         // From here on the reference counts the call in its statistics even when it fails (model.cpp:572-612).
         const auto t0 = std::chrono::steady_clock::now();
+        const RoctxRange range("ModelInfer:" + M.name);
         if (req.err.empty()) {
             if (batched) M.RunBatched(req);
             else { std::vector<ModelObj::Pending*> one{&req}; M.Execute(one); }
