@@ -287,7 +287,7 @@ def main() -> None:
                 hl.append(time.perf_counter() - t1)
             result["modelinfer_uint8_p50_ms"] = round(float(np.percentile(hl, 50)) * 1e3, 3)
             result["modelinfer_uint8_images_per_s"] = round(Bsz / float(np.percentile(hl, 50)), 1)
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:       # reported on rank 0 at N=1 only (the other ranks would idle behind it)
             # the numpy oracle needs ~0.5 s per image: keep its sample small
             nimg = args.cpu_sample if args.cpu_backend != "numpy" else min(args.cpu_sample, 8)
             result["cpu_baseline"] = cpu_baseline(nimg, args.model, args.cpu_backend)
