@@ -855,3 +855,22 @@ def test_uint8_ingest_matches_float_path(densenet_repo, tmp_path):
             np.testing.assert_array_equal(yshort, yref)
         finally:
             m.Destroy()
+
+
+def test_roctx_ranges_do_not_disturb_inference(model_repo):
+    """IE_ROCTX=1: the marker library is dlopen'ed and every ModelInfer call is wrapped in a range; results are unchanged."""
+    code = (
+        "import sys, os, numpy as np\n"
+        f"sys.path.insert(0, {ROOT!r}); sys.path.insert(0, os.path.join({ROOT!r}, 'tests'))\n"
+        "from _pkg import load_package; load_package()\n"
+        "from gpu_ai_inference_server_amd import binding as B\n"
+        f"m = B.CreateModel(os.path.join({model_repo!r}, 'test_model', '1'), 'test_model')\n"
+        "x = np.array([[-0.01349723, -1.0577109, 0.82254493]], np.float32)\n"
+        "y = m.Infer([B.TensorData('input', B.DataTypeFloat32, B.Shape([1, 3]), x)], [B.OutputConfig('output', [1, 2])])[0].Data\n"
+        "print('OUT', float(y[0]), float(y[1]))\n"
+        "m.Destroy()\n")
+    env = dict(os.environ, IE_ROCTX="1")
+    r = subprocess.run([os.sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = [ln for ln in r.stdout.splitlines() if ln.startswith("OUT")][0].split()
+    np.testing.assert_allclose([float(out[1]), float(out[2])], [-0.6017066, 1.8522782], rtol=2e-6)
