@@ -69,7 +69,7 @@ ABI_SYMBOLS = [
     "ModelLoad", "ModelUnload",
 ]
 EXT_SYMBOLS = ["EngineDescribeModel", "EnginePrepare", "EngineRunPrepared", "EngineSynchronize", "EngineGetStream",
-               "EngineProfile", "EngineGetWeightBlob", "EngineWeightsUpdated", "EngineGetPrecision", "EngineMemcpy", "EngineMfmaPeak", "EngineGetBatcherStats", "EngineVectorAdd"]
+               "EngineProfile", "EngineGetWeightBlob", "EngineWeightsUpdated", "EngineGetPrecision", "EngineMemcpy", "EngineMfmaPeak", "EngineGetBatcherStats", "EngineGetShardStats", "EngineVectorAdd"]
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -115,6 +115,7 @@ def lib() -> C.CDLL:
             "EngineMemcpy": (C.c_bool, [vp, vp, vp, C.c_size_t, C.c_int, ep]),
             "EngineMfmaPeak": (C.c_double, [C.c_int, C.c_int, C.c_int]),
             "EngineGetBatcherStats": (C.c_bool, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+            "EngineGetShardStats": (C.c_bool, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)   # AttributeError here = symbol missing from the .so
@@ -505,6 +506,14 @@ def WeightsUpdated(model: Model) -> None:
 
 def Precision(model: Model) -> str:
     return {0: "fp32", 1: "fp16"}.get(int(lib().EngineGetPrecision(model.handle)), "unloaded")
+
+
+def ShardStats(model: Model) -> tuple:
+    """(number of in-process replicas a request is sharded over, requests sharded so far)."""
+    n, calls = C.c_int(), C.c_int64()
+    if not lib().EngineGetShardStats(model.handle, C.byref(n), C.byref(calls)):
+        raise RuntimeError("shard stats unavailable")
+    return int(n.value), int(calls.value)
 
 
 def CopyToDevice(model: Model, dst_dev: int, src: np.ndarray) -> None:

@@ -26,6 +26,7 @@
 #include <mutex>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -96,6 +97,13 @@ struct ModelObj {
     std::shared_ptr<const ie::OnnxModel> onnx;
     ie::ModelInfo info;
     std::unique_ptr<ie::DeviceModel> dev;
+    // In-process batch sharding (single process, all GPUs of the node): extra replicas of the model on other devices.
+    // A request's rows are cut into contiguous slices, one per replica, run concurrently (one host thread per replica), and the
+    // result rows land at their offsets of the caller's output buffers.  IE_GPUS=<n> / config.json "gpus": n (devices
+    // device_id .. device_id+n-1) or IE_SHARD_DEVICES=<id,id,...> (explicit list; ids may repeat, which is how the single-GPU
+    // tests exercise the sharding logic).  Every replica uploads the packed weights itself (32 MB over PCIe, once, at load).
+    std::vector<std::unique_ptr<ie::DeviceModel>> replicas;     // replicas[k] serves slice k+1 (slice 0 is `dev`)
+    float u8_scale = 1.0f / 255.0f, u8_bias = 0.0f;
     int64_t load_time_ns = 0;
     std::atomic<int64_t> inference_count{0}, total_ns{0}, last_ns{0};
     std::atomic<size_t> memory_usage_bytes{0};
@@ -123,7 +131,7 @@ struct ModelObj {
     std::condition_variable bcv;
     std::deque<Pending*> queue;
     bool leader_active = false;
-    std::atomic<int64_t> device_batches{0}, coalesced_requests{0};
+    std::atomic<int64_t> device_batches{0}, coalesced_requests{0}, shard_calls{0};
 
     bool Load();      // model.cpp:503-548 + 825-871
     void Unload();    // model.cpp:618-648
@@ -193,6 +201,7 @@ bool ModelObj::Load() {
                         if (std::regex_search(txt, mm, std::regex("\"uint8_scale\"\\s*:\\s*" + num))) sc = std::stof(mm[1]);
                         if (std::regex_search(txt, mm, std::regex("\"uint8_bias\"\\s*:\\s*" + num))) bi = std::stof(mm[1]);
                         dm->SetU8Transform(sc, bi);
+                        u8_scale = sc; u8_bias = bi;
                     }
                 }
                 // Plan once at load (symbolic dims -> 1): rejects unsupported graphs here, like Ort::Session's
@@ -204,6 +213,36 @@ bool ModelObj::Load() {
                     shapes.push_back(s);
                 }
                 dm->Prepare(shapes);
+                std::vector<std::unique_ptr<ie::DeviceModel>> reps;
+                {
+                    std::vector<int> ids;
+                    if (const char* e = std::getenv("IE_SHARD_DEVICES")) {
+                        std::stringstream ss(e);
+                        std::string tok;
+                        while (std::getline(ss, tok, ',')) if (!tok.empty()) ids.push_back(std::atoi(tok.c_str()));
+                        if (!ids.empty()) ids.erase(ids.begin());           // the first id is the primary device's slice
+                    } else {
+                        int n = 1;
+                        if (const char* e = std::getenv("IE_GPUS")) n = std::atoi(e);
+                        else {
+                            std::ifstream cf(path + "/config.json");
+                            if (cf) {
+                                std::stringstream ss; ss << cf.rdbuf();
+                                const std::string txt = ss.str();
+                                std::smatch mm;
+                                if (std::regex_search(txt, mm, std::regex("\"gpus\"\\s*:\\s*(\\d+)"))) n = std::stoi(mm[1]);
+                            }
+                        }
+                        const int have = ie::HipDeviceCount();
+                        for (int k = 1; k < n && device_id + k < have; ++k) ids.push_back(device_id + k);
+                    }
+                    for (int id : ids) {
+                        auto r = std::make_unique<ie::DeviceModel>(parsed, id, prec);
+                        r->SetU8Transform(u8_scale, u8_bias);
+                        r->Prepare(shapes);
+                        reps.push_back(std::move(r));
+                    }
+                }
                 input_names.clear();
                 output_names.clear();
                 for (auto& vi : inf.inputs) input_names.push_back(vi.name);
@@ -231,6 +270,7 @@ bool ModelObj::Load() {
                 onnx = parsed;
                 info = std::move(inf);
                 dev = std::move(dm);
+                replicas = std::move(reps);
                 ok = true;
             } catch (const std::exception& e) {
                 last_error = std::string("ONNX model loading error: ") + e.what();
@@ -246,6 +286,7 @@ bool ModelObj::Load() {
 
 void ModelObj::Unload() {
     std::lock_guard<std::mutex> g(mu);
+    replicas.clear();
     dev.reset();
     onnx.reset();
     loaded = false;
@@ -535,6 +576,70 @@ void ModelObj::Execute(std::vector<Pending*>& batch) {
     auto fail_all = [&](const std::string& msg) { for (auto* r : batch) { r->ok = false; r->err = msg; } };
     if (!loaded.load() || !dev) { fail_all("Model not loaded"); return; }
     try {
+        if (batch.size() == 1 && !(batchable && max_batch > 1 && batch[0]->rows > 0) && !replicas.empty() && batchable) {
+            // ---- one request, rows sharded over the replicas (contiguous slices, like sharding.shard_batch) ----
+            Pending& r = *batch[0];
+            const int64_t rows = r.shapes.empty() || r.shapes[0].empty() ? 0 : r.shapes[0][0];
+            bool same_rows = rows > 0;
+            for (auto& sh : r.shapes) if (sh.empty() || sh[0] != rows) same_rows = false;
+            const int S = int(replicas.size()) + 1;
+            if (same_rows && rows >= S) {
+                std::vector<std::string> errs;
+                errs.resize(size_t(S));
+                std::vector<ie::PlanInstance*> pis;
+                pis.resize(size_t(S), nullptr);
+                auto run_slice = [&](int k) {
+                    try {
+                        ie::DeviceModel& D = k == 0 ? *dev : *replicas[size_t(k - 1)];
+                        const int64_t r0 = rows * k / S, r1 = rows * (k + 1) / S, nr = r1 - r0;
+                        std::vector<std::vector<int64_t>> shapes = r.shapes;
+                        for (auto& sh : shapes) sh[0] = nr;
+                        ie::PlanInstance& pi = D.Prepare(shapes);
+                        pis[size_t(k)] = &pi;
+                        std::vector<const void*> in_ptr(r.in_ptr.size(), nullptr);
+                        std::vector<size_t> in_bytes(r.in_ptr.size(), 0);
+                        for (size_t i = 0; i < r.in_ptr.size(); ++i) {
+                            const size_t row_bytes = size_t(pi.plan.inputs[i].view.numel() / nr) * (r.in_u8[i] ? 1 : sizeof(float));
+                            const size_t off = size_t(r0) * row_bytes;
+                            if (r.in_ptr[i] && r.in_bytes[i] > off) {
+                                in_ptr[i] = static_cast<const char*>(r.in_ptr[i]) + off;
+                                in_bytes[i] = std::min(r.in_bytes[i] - off, size_t(nr) * row_bytes);
+                            }
+                        }
+                        std::vector<void*> out_ptr;
+                        std::vector<size_t> out_bytes;
+                        for (int j = 0; j < r.num_outputs; ++j) {
+                            void* p = nullptr;
+                            size_t nb = 0;
+                            const TensorData& o = r.outputs[j];
+                            if (size_t(j) < pi.plan.outputs.size() && o.data_type == DATATYPE_FLOAT32 && o.data && o.data_size > 0) {
+                                const size_t row_bytes = size_t(pi.plan.outputs[size_t(j)].view.numel() / nr) * sizeof(float);
+                                const size_t off = size_t(r0) * row_bytes;
+                                if (o.data_size > off) {
+                                    p = static_cast<char*>(o.data) + off;
+                                    // the last slice also owns (zero-fills) whatever the caller's buffer has beyond the result
+                                    nb = k == S - 1 ? o.data_size - off : std::min(o.data_size - off, size_t(nr) * row_bytes);
+                                }
+                            }
+                            out_ptr.push_back(p);
+                            out_bytes.push_back(nb);
+                        }
+                        D.InferHost(pi, in_ptr, in_bytes, out_ptr, out_bytes, r.in_u8);
+                    } catch (const std::exception& e) {
+                        errs[size_t(k)] = e.what();
+                    }
+                };
+                std::vector<std::thread> workers;
+                for (int k = 1; k < S; ++k) workers.emplace_back(run_slice, k);
+                run_slice(0);
+                for (auto& w : workers) w.join();
+                for (auto& e : errs) if (!e.empty()) { fail_all("ONNX inference error: " + e); return; }
+                write_out_dims(r.outputs, r.num_outputs, pis[0]->plan.outputs, rows);
+                shard_calls.fetch_add(1);
+                r.ok = true;
+                return;
+            }
+        }
         if (batch.size() == 1 && !(batchable && max_batch > 1 && batch[0]->rows > 0)) {
             Pending& r = *batch[0];
             ie::PlanInstance& pi = dev->Prepare(r.shapes);
@@ -873,6 +978,15 @@ bool EngineGetBatcherStats(ModelHandle handle, int64_t* device_batches, int64_t*
     if (device_batches) *device_batches = M.device_batches.load();
     if (coalesced_requests) *coalesced_requests = M.coalesced_requests.load();
     if (max_batch) *max_batch = (M.batchable && M.max_batch > 1) ? M.max_batch : 0;
+    return true;
+}
+
+bool EngineGetShardStats(ModelHandle handle, int* num_shards, int64_t* sharded_calls) {
+    if (!handle) return false;
+    ModelObj& M = *handle->model;
+    std::lock_guard<std::mutex> g(M.mu);
+    if (num_shards) *num_shards = M.dev ? int(M.replicas.size()) + 1 : 0;
+    if (sharded_calls) *sharded_calls = M.shard_calls.load();
     return true;
 }
 

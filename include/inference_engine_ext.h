@@ -49,6 +49,10 @@ double EngineMfmaPeak(int nacc, int blocks_per_cu, int iters);
  * (0 = batching off for this model).  Enable with IE_DYNAMIC_BATCH=<rows> or config.json {"dynamic_batching": true,
  * "max_batch_size": N} or ModelCreate's ModelConfig fields; IE_BATCH_WINDOW_US sets the coalescing window (default 200). */
 bool EngineGetBatcherStats(ModelHandle handle, int64_t* device_batches, int64_t* coalesced_requests, int* max_batch);
+/* In-process batch sharding: number of model replicas a ModelInfer request is cut over (1 = off) and the number of requests that
+ * were sharded.  Enable with IE_GPUS=<n> or config.json {"gpus": n} (devices device_id .. device_id+n-1, clipped to the device count)
+ * or IE_SHARD_DEVICES=<id,id,...> (explicit list, ids may repeat).  Needs a graph with a symbolic batch axis. */
+bool EngineGetShardStats(ModelHandle handle, int* num_shards, int64_t* sharded_calls);
 /* result = a + b on the GPU for host arrays (the reference's VectorAdd smoke test, cuda_utils.cu:59-149). */
 bool EngineVectorAdd(const float* a, const float* b, float* result, size_t n, ErrorMessage* error);
 

@@ -874,3 +874,40 @@ def test_roctx_ranges_do_not_disturb_inference(model_repo):
     assert r.returncode == 0, r.stderr[-2000:]
     out = [ln for ln in r.stdout.splitlines() if ln.startswith("OUT")][0].split()
     np.testing.assert_allclose([float(out[1]), float(out[2])], [-0.6017066, 1.8522782], rtol=2e-6)
+
+
+def test_in_process_batch_sharding(densenet_repo):
+    """SURVEY §8e (single-process plan): a ModelInfer request is cut into contiguous row slices, one per model replica, run
+    concurrently and scattered back by offset.  On the 1-GPU box the replicas all live on device 0 (IE_SHARD_DEVICES=0,0,0), which
+    exercises the slicing / threading / scatter logic; uneven slices (7 rows over 3 replicas), FLOAT32 and UINT8 payloads."""
+    path = os.path.join(densenet_repo, "densenet_onnx", "1")
+    x = models.synthetic_input((7, 3, 224, 224), stream="shard")
+    xb = np.clip(x * 255.0, 0, 255).astype(np.uint8)
+    outs = [B.OutputConfig("fc6_1", Shape=[7, 1000, 1, 1], DataType="FLOAT32")]
+    m = B.CreateModel(path, "densenet_onnx")
+    try:
+        assert B.ShardStats(m) == (1, 0)
+        y1 = m.Infer([B.TensorData("data_0", B.DataTypeFloat32, B.Shape([7, 3, 224, 224]), x)], outs)[0].Data.copy()
+        y1u = m.Infer([B.TensorData("data_0", B.DataTypeUint8, B.Shape([7, 3, 224, 224]), xb)], outs)[0].Data.copy()
+    finally:
+        m.Destroy()
+    os.environ["IE_SHARD_DEVICES"] = "0,0,0"
+    try:
+        m = B.CreateModel(path, "densenet_onnx")
+        try:
+            assert B.ShardStats(m)[0] == 3
+            r = m.Infer([B.TensorData("data_0", B.DataTypeFloat32, B.Shape([7, 3, 224, 224]), x)], outs)[0]
+            y3 = r.Data.copy()
+            assert r.Shape.Dims == [7, 1000, 1, 1]
+            y3u = m.Infer([B.TensorData("data_0", B.DataTypeUint8, B.Shape([7, 3, 224, 224]), xb)], outs)[0].Data.copy()
+            assert B.ShardStats(m) == (3, 2)
+            # fewer rows than replicas: served by the primary alone
+            y2 = m.Infer([B.TensorData("data_0", B.DataTypeFloat32, B.Shape([2, 3, 224, 224]), x[:2])],
+                         [B.OutputConfig("fc6_1", Shape=[2, 1000, 1, 1], DataType="FLOAT32")])[0].Data.copy()
+            assert B.ShardStats(m) == (3, 2)
+        finally:
+            m.Destroy()
+    finally:
+        del os.environ["IE_SHARD_DEVICES"]
+    # slices run at other batch sizes (other tiles / summation orders): equal to the unsharded run up to fp32 rounding
+    assert rel_err(y3, y1) < 2e-5 and rel_err(y3u, y1u) < 2e-5 and rel_err(y2, y1.reshape(7, -1)[:2].reshape(-1)) < 2e-5
