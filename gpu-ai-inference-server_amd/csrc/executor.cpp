@@ -338,6 +338,12 @@ void DeviceModel::Autotune(PlanInstance& pi) {
     try {
         for (Step& s : pi.plan.steps) {
             if (s.kind != StepKind::Conv || s.algo == ConvAlgo::Naive || s.algo == ConvAlgo::Stem) continue;
+            // the planner's default may already name a specialised kernel: the search starts from the tiled implicit GEMM either way
+            if (s.algo == ConvAlgo::Ws1x1 || s.algo == ConvAlgo::Ws3x3 || s.algo == ConvAlgo::Direct || s.algo == ConvAlgo::Raster3x3) {
+                s.algo = ConvAlgo::IgemmVec;
+                s.tile = s.base_tile;
+                s.splitk = 1;
+            }
             const int64_t M = s.out.n * s.out.h * s.out.w, N = s.out.c;
             const int64_t bk = s.in.f16 ? 2 * kIgemmBK : kIgemmBK;
             const int64_t KT = s.algo == ConvAlgo::IgemmVec ? int64_t(s.kh) * s.kw * ((s.in.c + bk - 1) / bk)
@@ -499,12 +505,35 @@ ConvArgs DeviceModel::MakeConvArgs(const PlanInstance& pi, const Step& s) const 
     return a;
 }
 
-void DeviceModel::LaunchStep(const PlanInstance& pi, const Step& s, hipStream_t stream_) {
+void DeviceModel::LaunchStep(const PlanInstance& pi, const Step& s_in, hipStream_t stream_) {
+    const Step& s = s_in;
     const float* wb = d_weights_;
     auto wp = [&](int64_t off) -> const float* { return off >= 0 ? wb + off : nullptr; };
     switch (s.kind) {
         case StepKind::Conv: {
             ConvArgs a = MakeConvArgs(pi, s);
+            // A specialised launcher that declines this operand set (alignment, LDS budget ...) hands the step to the tiled kernel.
+            Step fb;
+            const Step* sp = &s_in;
+            {
+                bool ok = true;
+                switch (s_in.algo) {
+                    case ConvAlgo::Ws1x1: ok = s_in.in.f16 ? ConvWsEligible(a, s_in.tile) : ConvWs32Eligible(a, s_in.tile); break;
+                    case ConvAlgo::Ws3x3: ok = ConvWs3Eligible(a, s_in.tile); break;
+                    case ConvAlgo::Direct: ok = ConvDirectEligible(a, s_in.tile); break;
+                    case ConvAlgo::Raster3x3: ok = ConvRasterEligible(a, s_in.tile); break;
+                    case ConvAlgo::Stem: ok = ConvStemEligible(a); break;
+                    default: break;
+                }
+                if (!ok) {
+                    fb = s_in;
+                    fb.algo = s_in.algo == ConvAlgo::Stem ? ConvAlgo::IgemmScalar : ConvAlgo::IgemmVec;
+                    fb.tile = s_in.base_tile;
+                    fb.splitk = 1;
+                    sp = &fb;
+                }
+            }
+            const Step& s = *sp;
             // A fused residual Add lives in the weights-stationary 1x1 epilogues; any other kernel runs the conv without its ReLU
             // and adds the shortcut in place afterwards.
             const TensorArg res = a.res;

@@ -779,7 +779,58 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                 s.tile = choose_tile(M, N);
                 s.splitk = 1;
                 const int heuristic_tile = s.tile;
-                // Test / tuning overrides (read at plan time): IE_FORCE_TILE=<0..6>, IE_FORCE_ALGO=naive|scalar
+                s.base_tile = heuristic_tile;
+                // ---- plan-time eligibility of the specialised kernels (the launchers re-check pointers / alignment; the executor falls
+                //      back to the tiled implicit GEMM when a launcher declines) ----
+                const bool is1x1 = n.kh == 1 && n.kw == 1 && n.sh == 1 && n.sw == 1 && n.pt == 0 && n.pl == 0 && n.pb == 0 && n.pr == 0;
+                const bool is3x3 = n.kh == 3 && n.kw == 3 && n.sh == 1 && n.sw == 1 && n.pt == 1 && n.pl == 1 && n.pb == 1 && n.pr == 1;
+                static const int ws_tn[14] = {4, 4, 2, 2, 1, 1, 4, 4, 2, 2, 1, 1, 1, 1};      // 12, 13: fp32 K-split variants (8 / 4 waves)
+                auto ws16_ok = [&](int t) {
+                    return t >= 0 && t < 12 && vec16_ok && is1x1 && s.in.c % 32 == 0 &&
+                           (32 * ws_tn[t] * (s.in.c + 8) + 2 * s.in.c) * 2 + 128 * ws_tn[t] <= 160 * 1024 && !(ws_tn[t] > 1 && N <= 32 * (ws_tn[t] / 2)) &&
+                           (s.out.f16 ? (N % 8 == 0 && s.out.pitch % 8 == 0 && s.out.c_off % 8 == 0) : (N % 4 == 0 && s.out.pitch % 4 == 0 && s.out.c_off % 4 == 0));
+                };
+                auto ws32_ok = [&](int t) {
+                    return t >= 0 && t < 14 && vec_ok && !s.out.f16 && is1x1 && s.in.c % 16 == 0 &&
+                           (t < 12 ? (32 * ws_tn[t] * (s.in.c + 4) + 2 * s.in.c + 32 * ws_tn[t]) * 4 <= 160 * 1024
+                                   : (s.in.c / 16 >= (t == 12 ? 8 : 4) &&
+                                      (32 * (s.in.c + 4) + 2 * s.in.c + 32 + (t == 12 ? 4 : 2) * 32 * 36) * 4 <= 160 * 1024)) &&
+                           !(ws_tn[t] > 1 && N <= 32 * (ws_tn[t] / 2)) && N % 4 == 0 && s.out.pitch % 4 == 0 && s.out.c_off % 4 == 0;
+                };
+                static const int ws3_cfg[4][3] = {{4, 2, 12}, {4, 1, 8}, {8, 1, 6}, {2, 1, 12}};   // waves, row blocks per wave, prefetch depth
+                auto ws3_ok = [&](int t3) {
+                    if (t3 < 0 || t3 >= 4) return false;
+                    const int64_t pr3 = 32 * ws3_cfg[t3][1] * ws3_cfg[t3][0] + 2 * (s.in.w + 1) + 2;
+                    return vec16_ok && s.out.f16 && is3x3 && !n.has_pre && N <= 32 && N % 8 == 0 && s.out.pitch % 8 == 0 && s.out.c_off % 8 == 0 &&
+                           pr3 <= ws3_cfg[t3][2] * (64 * ws3_cfg[t3][0] / 8) && (9 * ((s.in.c + 63) / 64) * 32 + pr3) * 144 + 128 <= 160 * 1024;
+                };
+                static const int dcfg[6][3] = {{1, 8, 8}, {1, 16, 4}, {1, 9, 8}, {1, 4, 8}, {1, 12, 6}, {2, 8, 4}};   // tn, waves, max chunks
+                auto direct_ok = [&](int t) {
+                    if (t < 0 || t >= 6) return false;
+                    const int cw = in16 ? 32 : 16, al = in16 ? 8 : 4;
+                    const int64_t total = s.in.c % cw == 0 ? int64_t(n.kh) * n.kw * (s.in.c / cw) : 0;
+                    return (vec_ok || vec16_ok) && s.in.c % cw == 0 && s.in.pitch % al == 0 && s.in.c_off % al == 0 && N % 2 == 0 && s.out.pitch % 2 == 0 &&
+                           s.out.c_off % 2 == 0 && total >= dcfg[t][1] && total <= dcfg[t][1] * dcfg[t][2] && !(dcfg[t][0] > 1 && N <= 32) && M <= 65536 &&
+                           n.kh * n.kw <= 49;
+                };
+                const bool raster_ok = vec_ok && !s.out.f16 && is3x3 && !n.has_pre;
+                // ---- default choice without the autotuner (IE_AUTOTUNE=0, or before Prepare() has timed anything): the kernels
+                //      the exhaustive search picks for DenseNet / ResNet shapes ----
+                if (!std::getenv("IE_FORCE_ALGO") && !std::getenv("IE_FORCE_TILE") && s.algo == ConvAlgo::IgemmVec) {
+                    int pick = -1;
+                    if (M <= 2048) {                                                       // tiny grids: split K over the waves
+                        for (int t : {1, 0, 4, 3}) if (pick < 0 && direct_ok(t)) pick = t;
+                        if (pick >= 0) { s.algo = ConvAlgo::Direct; s.tile = pick; }
+                    } else if (in16) {
+                        if (is1x1) { for (int t : {0, 2, 4}) if (pick < 0 && ws16_ok(t)) pick = t; if (pick >= 0) { s.algo = ConvAlgo::Ws1x1; s.tile = pick; } }
+                        else if (is3x3) { for (int t : {2, 1, 0}) if (pick < 0 && ws3_ok(t)) pick = t; if (pick >= 0) { s.algo = ConvAlgo::Ws3x3; s.tile = pick; } }
+                    } else {
+                        if (is1x1 && M >= 20000) { for (int t : {0, 2, 4}) if (pick < 0 && ws32_ok(t)) pick = t; if (pick >= 0) { s.algo = ConvAlgo::Ws1x1; s.tile = pick; } }
+                        else if (raster_ok && M >= 20000 && N <= 64) { s.algo = ConvAlgo::Raster3x3; s.tile = N <= 32 ? 0 : 4; }
+                        else if (is3x3 && M <= 8192) { if (direct_ok(4)) { s.algo = ConvAlgo::Direct; s.tile = 4; } }
+                    }
+                }
+                // Test / tuning overrides (read at plan time): IE_FORCE_TILE=<n>, IE_FORCE_ALGO=naive|scalar|igemm|raster|ws|direct
                 if (const char* fa = std::getenv("IE_FORCE_ALGO")) {
                     std::string f = fa;
                     if (f == "naive") s.algo = ConvAlgo::Naive;
@@ -790,43 +841,18 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                     else if (f == "ws") {
                         int t = 0;
                         if (const char* ft = std::getenv("IE_FORCE_TILE")) { int v = std::atoi(ft); if (v >= 0 && v < (in16 ? 12 : 14)) t = v; }
-                        static const int ws_tn[14] = {4, 4, 2, 2, 1, 1, 4, 4, 2, 2, 1, 1, 1, 1};      // 12, 13: fp32 K-split variants (8 / 4 waves)
-                        const bool eligible = vec16_ok && n.kh == 1 && n.kw == 1 && n.sh == 1 && n.sw == 1 && n.pt == 0 && n.pl == 0 && n.pb == 0 &&
-                                              n.pr == 0 && s.in.c % 32 == 0 && (32 * ws_tn[t] * (s.in.c + 8) + 2 * s.in.c) * 2 + 128 * ws_tn[t] <= 160 * 1024 &&
-                                              !(ws_tn[t] > 1 && N <= 32 * (ws_tn[t] / 2));
-                        static const int ws3_cfg[4][3] = {{4, 2, 12}, {4, 1, 8}, {8, 1, 6}, {2, 1, 12}};   // waves, row blocks per wave, prefetch depth
-                        const int t3 = t % 4;
-                        const int64_t pr3 = 32 * ws3_cfg[t3][1] * ws3_cfg[t3][0] + 2 * (s.in.w + 1) + 2;
-                        const bool eligible3 = vec16_ok && s.out.f16 && n.kh == 3 && n.kw == 3 && n.sh == 1 && n.sw == 1 && n.pt == 1 && n.pl == 1 &&
-                                               n.pb == 1 && n.pr == 1 && !n.has_pre && N <= 32 && N % 8 == 0 && s.out.pitch % 8 == 0 && s.out.c_off % 8 == 0 &&
-                                               pr3 <= ws3_cfg[t3][2] * (64 * ws3_cfg[t3][0] / 8) &&
-                                               (9 * ((s.in.c + 63) / 64) * 32 + pr3) * 144 + 128 <= 160 * 1024;
-                        const bool eligible32 = vec_ok && !s.out.f16 && n.kh == 1 && n.kw == 1 && n.sh == 1 && n.sw == 1 && n.pt == 0 && n.pl == 0 &&
-                                                n.pb == 0 && n.pr == 0 && s.in.c % 16 == 0 &&
-                                                (t < 12 ? (32 * ws_tn[t] * (s.in.c + 4) + 2 * s.in.c + 32 * ws_tn[t]) * 4 <= 160 * 1024
-                                                        : (s.in.c / 16 >= (t == 12 ? 8 : 4) &&
-                                                           (32 * (s.in.c + 4) + 2 * s.in.c + 32 + (t == 12 ? 4 : 2) * 32 * 36) * 4 <= 160 * 1024)) &&
-                                                !(ws_tn[t] > 1 && N <= 32 * (ws_tn[t] / 2)) && N % 4 == 0 && s.out.pitch % 4 == 0 && s.out.c_off % 4 == 0;
-                        if (eligible || eligible32) { s.algo = ConvAlgo::Ws1x1; s.tile = t; }
-                        else if (eligible3) { s.algo = ConvAlgo::Ws3x3; s.tile = t3; }
+                        if (ws16_ok(t) || ws32_ok(t)) { s.algo = ConvAlgo::Ws1x1; s.tile = t; }
+                        else if (ws3_ok(t % 4)) { s.algo = ConvAlgo::Ws3x3; s.tile = t % 4; }
                         else if (s.algo == ConvAlgo::Naive && vec16_ok) s.algo = ConvAlgo::IgemmVec;
                     }
                     else if (f == "direct") {
                         int t = 0;
                         if (const char* ft = std::getenv("IE_FORCE_TILE")) { int v = std::atoi(ft); if (v >= 0 && v < 6) t = v; }
-                        static const int dcfg[6][3] = {{1, 8, 8}, {1, 16, 4}, {1, 9, 8}, {1, 4, 8}, {1, 12, 6}, {2, 8, 4}};   // tn, waves, max chunks
-                        const int cw = in16 ? 32 : 16, al = in16 ? 8 : 4;
-                        const int64_t total = s.in.c % cw == 0 ? int64_t(n.kh) * n.kw * (s.in.c / cw) : 0;
-                        const bool eligible = (vec_ok || vec16_ok) && s.in.c % cw == 0 && s.in.pitch % al == 0 && s.in.c_off % al == 0 && N % 2 == 0 &&
-                                              s.out.pitch % 2 == 0 && s.out.c_off % 2 == 0 && total >= dcfg[t][1] && total <= dcfg[t][1] * dcfg[t][2] &&
-                                              !(dcfg[t][0] > 1 && N <= 32) && M <= 65536 && n.kh * n.kw <= 49;
-                        if (eligible) { s.algo = ConvAlgo::Direct; s.tile = t; }
+                        if (direct_ok(t)) { s.algo = ConvAlgo::Direct; s.tile = t; }
                         else if (s.algo == ConvAlgo::Naive && (vec_ok || vec16_ok)) s.algo = ConvAlgo::IgemmVec;
                     }
                     else if (f == "raster") {
-                        const bool eligible = vec_ok && n.kh == 3 && n.kw == 3 && n.sh == 1 && n.sw == 1 && n.pt == 1 && n.pl == 1 &&
-                                              n.pb == 1 && n.pr == 1 && !n.has_pre;
-                        if (eligible) {
+                        if (raster_ok) {
                             s.algo = ConvAlgo::Raster3x3;
                             s.tile = 0;
                             if (const char* ft = std::getenv("IE_FORCE_TILE")) { int t = std::atoi(ft); if (t >= 0 && t < 8) s.tile = t; }

@@ -64,6 +64,7 @@ struct Step {
     bool relu = false;         // applied to the result
     ConvAlgo algo = ConvAlgo::Naive;
     int tile = 0;              // igemm tile configuration index (see igemm_tiles.h)
+    int base_tile = 0;         // the tiled implicit GEMM's heuristic tile (what the executor falls back to when a specialised launcher declines)
     int splitk = 1;            // >1: K-tiles split over this many workgroups per output tile (+ reduce kernel)
     double flops = 0;          // algorithmic FLOPs (2*MACs) of this step for the planned shape
     double bytes = 0;          // algorithmic bytes: operands read once + result written once
