@@ -313,7 +313,8 @@ hipError_t InitKernelsWs() {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// Weights-stationary 3x3 / stride 1 / pad 1 convolution for the fp16 mode (DenseNet's growth convs: Cin = 128, Cout = 32).
+// Weights-stationary 3x3 / stride 1 / pad 1 convolution for the fp16 mode (DenseNet's growth convs: Cin = 128, Cout = 32; wider
+// layers such as ResNet's 64->64 and 128->128 run one 32-channel N-tile per blockIdx.y, each with its own resident weights).
 //
 // Same 1-D raster of the zero-padded image stack as conv3x3_raster_kernel (kernels.hip): raster index
 // p = (b*RH + y)*PW + x with PW = W + 1, RH = H + 1, and tap (ky, kx) of output position p reads raster position
@@ -346,6 +347,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_ws_f16_kernel(const ConvAr
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Cin = a.in.c, H = a.in.h, W = a.in.w, Cout = a.out.c;
+    const int n0 = blockIdx.y * 32;                   // output-channel tile (wider layers: one resident weight set per N-tile)
     const int img = g.RH * PW, Mr = a.in.n * img;
     const int isw = int(a.in.sw), opitch = int(a.out.sw);
 
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_ws_f16_kernel(const ConvAr
                 const int n = row & 31, ts = row >> 5;
                 const int tap = ts / NS, sl = ts - tap * NS;
                 const int c = sl * 64 + ck * 8;
-                const unsigned off = (q < items && n < Cout && c < Cin) ? unsigned((n * 9 + tap) * Cin + c) * 2u : 0x80000000u;
+                const unsigned off = (q < items && n0 + n < Cout && c < Cin) ? unsigned(((n0 + n) * 9 + tap) * Cin + c) * 2u : 0x80000000u;
                 v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0);
             }
 #pragma unroll
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_ws_f16_kernel(const ConvAr
                 if (q < items) *reinterpret_cast<u32x4*>(sW + (q >> 3) * LDP + (q & 7) * 8) = v[u];
             }
         }
-        for (int q = tid; q < 32; q += NT) sBias[q] = (a.bias != nullptr && q < Cout) ? a.bias[q] : 0.f;
+        for (int q = tid; q < 32; q += NT) sBias[q] = (a.bias != nullptr && n0 + q < Cout) ? a.bias[n0 + q] : 0.f;
     }
 
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(a.in.p, 0, int(a.in_bytes), 0x00020000);
@@ -471,7 +473,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_ws_f16_kernel(const ConvAr
                 const u32x2 xa = __builtin_bit_cast(u32x2, qa), xb = __builtin_bit_cast(u32x2, qb);
                 const auto s0 = __builtin_amdgcn_permlane32_swap(xa[0], xb[0], false, false);
                 const auto s1 = __builtin_amdgcn_permlane32_swap(xa[1], xb[1], false, false);
-                const int n = 8 * (2 * gp + hh);
+                const int n = n0 + 8 * (2 * gp + hh);
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rs_out, n < Cout ? rowoff + unsigned(n * 2) : OOB, 0, 0);
             }
         }
@@ -518,7 +520,7 @@ bool ConvWs3Eligible(const ConvArgs& a, int tile) {
     if (a.in.sc != 1 || a.out.sc != 1 || (a.in.c & 7) || (a.in.sw & 7) || (reinterpret_cast<uintptr_t>(a.in.p) & 15) ||
         (reinterpret_cast<uintptr_t>(a.w16) & 15))
         return false;
-    if (a.out.c > 32 || (a.out.c & 7) || (a.out.sw & 7) || (reinterpret_cast<uintptr_t>(a.out.p) & 15)) return false;
+    if ((a.out.c & 7) || (a.out.sw & 7) || (reinterpret_cast<uintptr_t>(a.out.p) & 15)) return false;      // any Cout, 32 per N-tile
     if (a.in.sh != a.in.sw * a.in.w || a.in.sn != a.in.sh * a.in.h) return false;          // pixel-major NHWC views
     if (a.out.sh != a.out.sw * a.out.w || a.out.sn != a.out.sh * a.out.h) return false;
     const int64_t Mr = int64_t(a.in.n) * (a.in.h + 1) * (a.in.w + 1), Mpix = int64_t(a.in.n) * a.in.h * a.in.w;
@@ -559,10 +561,12 @@ static hipError_t launch_ws3_t(const ConvArgs& a, hipStream_t stream) {
     }
     int per_cu = int((size_t(160) * 1024) / lds);
     per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
-    const int slots = cus * per_cu;
+    const int gy = (a.out.c + 31) / 32;
+    int slots = cus * per_cu / gy;                     // resident workgroups per N-tile
+    if (slots < 1) slots = 1;
     const int iters = (g.num_tiles + slots - 1) / slots;
     const int gx = (g.num_tiles + iters - 1) / iters;
-    conv3x3_ws_f16_kernel<t.waves, t.tmw, t.pit><<<dim3(gx), dim3(64 * t.waves), lds, stream>>>(a, g);
+    conv3x3_ws_f16_kernel<t.waves, t.tmw, t.pit><<<dim3(gx, gy), dim3(64 * t.waves), lds, stream>>>(a, g);
     return hipGetLastError();
 }
 

@@ -801,7 +801,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                 auto ws3_ok = [&](int t3) {
                     if (t3 < 0 || t3 >= 4) return false;
                     const int64_t pr3 = 32 * ws3_cfg[t3][1] * ws3_cfg[t3][0] + 2 * (s.in.w + 1) + 2;
-                    return vec16_ok && s.out.f16 && is3x3 && !n.has_pre && N <= 32 && N % 8 == 0 && s.out.pitch % 8 == 0 && s.out.c_off % 8 == 0 &&
+                    return vec16_ok && s.out.f16 && is3x3 && !n.has_pre && N % 8 == 0 && s.out.pitch % 8 == 0 && s.out.c_off % 8 == 0 &&
                            pr3 <= ws3_cfg[t3][2] * (64 * ws3_cfg[t3][0] / 8) && (9 * ((s.in.c + 63) / 64) * 32 + pr3) * 144 + 128 <= 160 * 1024;
                 };
                 static const int dcfg[6][3] = {{1, 8, 8}, {1, 16, 4}, {1, 9, 8}, {1, 4, 8}, {1, 12, 6}, {2, 8, 4}};   // tn, waves, max chunks

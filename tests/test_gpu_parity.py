@@ -778,6 +778,31 @@ def test_unknown_precision_is_a_load_error(model_repo):
 # classifier.  The reference holds no ResNet file or output, so this family is "parity unpinned" by the reference as well: the
 # checker is the float64 oracle on the same synthetic graph.
 # ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tile", range(4))
+def test_fp16_weights_stationary_3x3_wide_outputs(tmp_path, tile):
+    """conv3x3_ws_f16_kernel with more than 32 output channels (one resident weight set per 32-channel N-tile, blockIdx.y): the
+    64->64 and 128->128 3x3 convs of a ResNet, every tile variant."""
+    mb = models.resnet(2, layers=(2, 2, 1, 1), width=64, image=64, classes=20, seed=52)
+    path = models.write_repo(str(tmp_path), "resnet_ws3", mb)
+    om = O.load_model(mb)
+    x = models.synthetic_input((2, 3, 64, 64), stream="resnet_ws3")
+    ref = O.run(om, {"data": x}, dtype=np.float64)["logits"]
+
+    def go():
+        plan = B.DescribeModel(path, 2)["plan"]
+        n3 = [st for st in plan["steps"] if st.get("algo") == "ws3x3"]
+        m = B.CreateModel(path, "resnet_ws3")
+        try:
+            return n3, infer(m, "", "data", x, "logits", [2, 20])[0]
+        finally:
+            m.Destroy()
+    n3, y = _run_with_env(dict(IE_PRECISION="fp16", IE_FORCE_ALGO="ws", IE_FORCE_TILE=str(tile)), go)
+    assert len(n3) >= 3 and {st["out"]["c"] for st in n3} >= {64, 128}, [(st["in"]["c"], st["out"]["c"]) for st in n3]
+    e = rel_err(y, ref)
+    print(f"ws3x3 wide tile {tile}: {len(n3)} convs, rel err {e:.2e}")
+    assert e < F16_RTOL
+
+
 @pytest.mark.parametrize("prec", ["fp32", "fp16"])
 def test_resnet_mini_vs_float64_oracle(tmp_path, prec):
     mb = models.resnet(3, layers=(2, 2, 2, 2), width=16, image=64, classes=20, seed=51)
