@@ -246,6 +246,11 @@ PlanInstance& DeviceModel::Prepare(const std::vector<std::vector<int64_t>>& shap
     // Sub-batch split: every graph input shares the leading batch dimension and it divides evenly.
     int nsub = sub_streams_;
     int64_t batch = shapes.empty() || shapes[0].empty() ? 0 : shapes[0][0];
+    // Measured on MI355X (DenseNet-121): in fp16 mode the per-launch fixed costs (weight preamble, first loads, store drain) are half
+    // of the forward, and two half-batches on two streams (IE_STREAMS=2) overlap them in back-to-back replays: batch 128 52.6k ->
+    // 56.2k images/s (4 streams: 43k; fp32 batch 32: 10.77k -> 10.57k).
+    // It is NOT the default: a single call's latency gets worse (p50 2.39 -> 2.65 ms per 128-image step, ModelInfer with UINT8
+    // payloads 3.50 -> 3.65 ms) and the ABI path serves one request per model at a time.  IE_STREAMS=2 opts in.
     for (auto& s : shapes) if (s.empty() || s[0] != batch) nsub = 1;
     if (batch < 2 * nsub || batch % nsub != 0) nsub = 1;
 
