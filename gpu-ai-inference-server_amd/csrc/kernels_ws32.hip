@@ -9,6 +9,8 @@
 // four MFMAs.  D = W x A^T: a lane owns one pixel and quads of channels -> 16-byte stores.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace ie {
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_ws_f32_kernel(const ConvAr
         constexpr int U = 8;
         const int k4 = K >> 2;
         const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, Cout * K * 4, 0x00020000);
-        for (int idx0 = tid; idx0 < BN * k4; idx0 += U * NT) {
+        for (int idx0 = tid; idx0 < ((a.debug & 128) ? 0 : BN * k4); idx0 += U * NT) {      // debug 128: timing-only, no weight preamble
             u32x4 v[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -125,8 +127,10 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_ws_f32_kernel(const ConvAr
                 const int q1 = (st + 1) / TN, j1 = (st + 1) % TN;
                 bfr[(st + 1) & 1] = *reinterpret_cast<const f32x4*>(Bp + j1 * 32 * P + q1 * 8);
             }
+            if (!(a.debug & 64)) {                          // debug 64: timing-only, no MFMAs
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[st & 1][e], av[q][e], acc[j], 0, 0, 0);
+                for (int e = 0; e < 4; ++e) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[st & 1][e], av[q][e], acc[j], 0, 0, 0);
+            }
             // pin the order "next fragment read, then this step's four MFMAs" (the scheduler otherwise sinks the read to its use)
             if (st + 1 < 2 * TN) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
@@ -156,7 +160,8 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_ws_f32_kernel(const ConvAr
                     v[q] = a.relu ? fmaxf(x, 0.f) : x;
                     acc[j][4 * g + q] = 0.f;
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_out, n0 + nl < Cout ? rowoff + unsigned((n0 + nl) * 4) : OOB, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_out,
+                                                       (n0 + nl < Cout && !(a.debug & 32)) ? rowoff + unsigned((n0 + nl) * 4) : OOB, 0, 0);   // debug 32: no stores
             }
         }
     };
@@ -436,6 +441,8 @@ static hipError_t launch_ws32_t(const ConvArgs& a, bool one_per_wave, hipStream_
 hipError_t LaunchConvWs1x1F32(const ConvArgs& a_in, int tile, hipStream_t stream) {
     if (!ConvWs32Eligible(a_in, tile)) return hipErrorInvalidValue;
     ConvArgs a = a_in;
+    static const int dbg = [] { const char* e = std::getenv("IE_DEBUG_ABLATE"); return e ? std::atoi(e) : 0; }();
+    a.debug = dbg;                                     // timing-only ablations (wrong results): 32 no stores, 64 no MFMAs, 128 no weight preamble
     a.in_bytes = 4 * (int64_t(a.in.n - 1) * a.in.sn + int64_t(a.in.h - 1) * a.in.sh + int64_t(a.in.w - 1) * a.in.sw + int64_t(a.in.c - 1) + 1);
     if (tile == kNumConvWsTiles) return a.pre_scale ? launch_wsk32_t<8, true>(a, stream) : launch_wsk32_t<8, false>(a, stream);
     if (tile == kNumConvWsTiles + 1) return a.pre_scale ? launch_wsk32_t<4, true>(a, stream) : launch_wsk32_t<4, false>(a, stream);
