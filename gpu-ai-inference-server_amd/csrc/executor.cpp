@@ -154,6 +154,7 @@ DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id, 
         }
     }
     if (const char* ns = std::getenv("IE_STREAMS")) sub_streams_ = std::max(1, std::min(8, std::atoi(ns)));
+    if (const char* mp = std::getenv("IE_MAX_PLANS")) max_plans_ = size_t(std::max(1, std::atoi(mp)));
     for (int i = 1; i < sub_streams_; ++i) {
         hipStream_t st = nullptr;
         check(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
@@ -239,8 +240,22 @@ void DeviceModel::BuildInstance(PlanInstance& pi, const std::vector<std::vector<
 PlanInstance& DeviceModel::Prepare(const std::vector<std::vector<int64_t>>& shapes) {
     std::vector<int64_t> key;
     for (auto& s : shapes) { key.push_back(int64_t(s.size())); key.insert(key.end(), s.begin(), s.end()); }
+    auto touch = [&](const std::vector<int64_t>& k) {
+        for (size_t i = 0; i < lru_.size(); ++i) if (lru_[i] == k) { lru_.erase(lru_.begin() + long(i)); break; }
+        lru_.push_back(k);
+    };
     auto it = plans_.find(key);
-    if (it != plans_.end()) { current_ = it->second.get(); return *current_; }
+    if (it != plans_.end()) { touch(key); current_ = it->second.get(); return *current_; }
+    while (plans_.size() >= max_plans_ && !lru_.empty()) {        // make room: drop the least recently used instance
+        check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+        auto old = plans_.find(lru_.front());
+        if (old != plans_.end()) {
+            if (current_ == old->second.get()) current_ = nullptr;
+            FreeInstance(*old->second);
+            plans_.erase(old);
+        }
+        lru_.erase(lru_.begin());
+    }
 
     check(hipSetDevice(device_), "hipSetDevice");
     // Sub-batch split: every graph input shares the leading batch dimension and it divides evenly.
@@ -325,6 +340,7 @@ PlanInstance& DeviceModel::Prepare(const std::vector<std::vector<int64_t>>& shap
     }
     current_ = pi.get();
     plans_[key] = std::move(pi);
+    touch(key);
     return *current_;
 }
 

@@ -133,6 +133,11 @@ private:
     bool two_pass_splitk_ = true;      // IE_SPLITK_IN_LAUNCH=1 selects the in-launch combine instead of the reduce kernel
     std::map<std::vector<int64_t>, std::pair<int, int>> tune_cache_;   // conv signature -> (tile, splitk)
     std::map<std::vector<int64_t>, std::unique_ptr<PlanInstance>> plans_;
+    // Least-recently-used order of the plan keys (front = oldest).  A server that sees many distinct batch sizes would otherwise keep
+    // one set of activation buffers + one hipGraph per size forever; beyond IE_MAX_PLANS (default 8) the oldest instance is freed
+    // (its autotune results stay in tune_cache_, so re-creating it is cheap).
+    std::vector<std::vector<int64_t>> lru_;
+    size_t max_plans_ = 8;
     PlanInstance* current_ = nullptr;
     std::unique_ptr<CopyPool> copy_pool_;
     void* pinned_ = nullptr;           // pinned host staging ring for H2D/D2H

@@ -936,3 +936,28 @@ def test_in_process_batch_sharding(densenet_repo):
         del os.environ["IE_SHARD_DEVICES"]
     # slices run at other batch sizes (other tiles / summation orders): equal to the unsharded run up to fp32 rounding
     assert rel_err(y3, y1) < 2e-5 and rel_err(y3u, y1u) < 2e-5 and rel_err(y2, y1.reshape(7, -1)[:2].reshape(-1)) < 2e-5
+
+
+def test_plan_cache_is_bounded(model_repo):
+    """A server sees arbitrary batch sizes: plan instances (activation buffers + hipGraph per input shape) are kept in an LRU of
+    IE_MAX_PLANS entries; evicted shapes are rebuilt on demand with identical results."""
+    mb = models.densenet("N", growth=8, blocks=(2, 2), stem=16, image=32, classes=10, seed=9)
+
+    def go(tmp):
+        path = models.write_repo(tmp, "lru", mb)
+        m = B.CreateModel(path, "lru")
+        try:
+            outs = {}
+            for rep in range(2):
+                for b in (1, 2, 3, 4, 5):
+                    x = models.synthetic_input((b, 3, 32, 32), stream=f"lru{b}")
+                    y, _ = infer(m, "", "data_0", x, "fc6_1", [b, 10, 1, 1])
+                    if rep == 0:
+                        outs[b] = y.copy()
+                    else:
+                        np.testing.assert_array_equal(y, outs[b])       # rebuilt after eviction: same plan, same kernels, same bits
+        finally:
+            m.Destroy()
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        _run_with_env(dict(IE_MAX_PLANS="2", IE_AUTOTUNE="0"), lambda: go(tmp))
