@@ -176,6 +176,7 @@ DeviceModel::~DeviceModel() {
     for (auto st : side_streams_) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     if (d_weights_) (void)hipFree(d_weights_);
     if (d_weights16_) (void)hipFree(d_weights16_);
+    if (d_weights_frag_) (void)hipFree(d_weights_frag_);
     if (pinned_) (void)hipHostFree(pinned_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -204,8 +205,16 @@ void DeviceModel::BuildInstance(PlanInstance& pi, const std::vector<std::vector<
         if (precision_ == Precision::F16) {
             check(hipMalloc(&d_weights16_, std::max<size_t>(weight_floats_, 8) * 2), "hipMalloc(weights16)");
             device_bytes_ += weight_floats_ * 2;
-            RefreshHalfWeights();
+        } else if (!std::getenv("IE_NO_FRAG_WEIGHTS")) {
+            for (const Step& st : pi.plan.steps)
+                if (st.kind == StepKind::Conv && st.w_off >= 0 && st.out.c % 16 == 0 && st.in.c % 16 == 0 && st.kh * st.kw <= 49)
+                    frag_regions_.push_back({st.w_off, int(st.out.c), st.kh * st.kw, int(st.in.c)});
+            if (!frag_regions_.empty()) {
+                check(hipMalloc(reinterpret_cast<void**>(&d_weights_frag_), weight_floats_ * sizeof(float)), "hipMalloc(weights_frag)");
+                device_bytes_ += weight_floats_ * sizeof(float);
+            }
         }
+        RefreshHalfWeights();
     } else if (pi.plan.weights.size() != weight_floats_) {
         throw std::runtime_error("internal error: weight blob layout depends on the input shape");
     }
@@ -344,10 +353,14 @@ PlanInstance& DeviceModel::Prepare(const std::vector<std::vector<int64_t>>& shap
     return *current_;
 }
 
+// Rebuilds what is derived from the fp32 weight blob: the half mirror (fp16 mode) or the fragment-major conv weights (fp32 mode).
 void DeviceModel::RefreshHalfWeights() {
-    if (!d_weights16_) return;
+    if (!d_weights16_ && !d_weights_frag_) return;
     check(hipSetDevice(device_), "hipSetDevice");
-    check(LaunchConvertF32ToF16(d_weights_, d_weights16_, int64_t(weight_floats_), stream_), "convert_f32_f16");
+    if (d_weights16_) check(LaunchConvertF32ToF16(d_weights_, d_weights16_, int64_t(weight_floats_), stream_), "convert_f32_f16");
+    if (d_weights_frag_)
+        for (const FragRegion& fr : frag_regions_)
+            check(LaunchPermuteWeightsFrag(d_weights_ + fr.w_off, d_weights_frag_ + fr.w_off, fr.cout, fr.kk, fr.cin, stream_), "permute_weights_frag");
     check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
 }
 
@@ -510,6 +523,7 @@ ConvArgs DeviceModel::MakeConvArgs(const PlanInstance& pi, const Step& s) const 
     if (s.has_in2) a.res = make_arg(pi, s.in2);
     a.w = wp(s.w_off);
     a.w16 = d_weights16_ && s.w_off >= 0 ? static_cast<const char*>(d_weights16_) + s.w_off * 2 : nullptr;
+    a.wfrag = d_weights_frag_ && s.w_off >= 0 && s.out.c % 16 == 0 && s.in.c % 16 == 0 && s.kh * s.kw <= 49 ? d_weights_frag_ + s.w_off : nullptr;
     a.bias = wp(s.bias_off);
     a.pre_scale = wp(s.pre_scale_off);
     a.pre_shift = wp(s.pre_shift_off);

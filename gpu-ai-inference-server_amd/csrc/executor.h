@@ -122,6 +122,9 @@ private:
     hipStream_t stream_ = nullptr;
     float* d_weights_ = nullptr;
     void* d_weights16_ = nullptr;      // fp16 mode: the same blob as halfs, same element offsets
+    float* d_weights_frag_ = nullptr;  // fp32 mode: conv weights again in MFMA-fragment order at the same offsets (window kernels)
+    struct FragRegion { int64_t w_off; int cout, kk, cin; };
+    std::vector<FragRegion> frag_regions_;
     Precision precision_ = Precision::F32;
     size_t weight_floats_ = 0;
     size_t device_bytes_ = 0;

@@ -23,6 +23,7 @@ struct ConvArgs {
     TensorArg res;                     // res.p != null: out = act(conv + bias + res), res has the output's shape (residual Add fused)
     const float* w = nullptr;          // [Cout][kh][kw][Cin]
     const void* w16 = nullptr;         // the same weights as halfs at the same element offset (fp16 precision mode)
+    const float* wfrag = nullptr;      // fragment-major fp32 mirror of w (LaunchPermuteWeightsFrag), or null
     const float* bias = nullptr;       // [Cout] or null
     const float* pre_scale = nullptr;  // [Cin] or null: x <- x*scale + shift (then ReLU if pre_relu) before the conv
     const float* pre_shift = nullptr;
@@ -92,7 +93,9 @@ hipError_t LaunchConvWs3x3F16(const ConvArgs& a, int tile, hipStream_t stream);
 hipError_t InitKernelsWs3();
 // "Direct split-K" conv for small output grids (kernels_direct.hip): K split over the waves of a workgroup, both operands loaded
 // straight from global memory into MFMA fragments (all at once), partial tiles summed through LDS.  fp32 and fp16.
-constexpr int kNumConvDirectTiles = 6;
+constexpr int kNumDirectBaseTiles = 6;     // tiles 0..5: both operands straight from global memory
+constexpr int kNumConvDirectTiles = 10;    // tiles 6..9: "window" variants (fp32, 16x16x4 MFMA tiles): activations through LDS, fragment-major weights
+hipError_t LaunchPermuteWeightsFrag(const float* src, float* dst, int Cout, int KK, int Cin, hipStream_t stream);
 bool ConvDirectEligible(const ConvArgs& a, int tile);
 hipError_t LaunchConvDirect(const ConvArgs& a, int tile, hipStream_t stream);
 hipError_t InitKernelsDirect();

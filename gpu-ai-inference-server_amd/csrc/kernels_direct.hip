@@ -16,6 +16,8 @@
 // channels) variants share the structure.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace ie {
@@ -196,8 +198,209 @@ __global__ __launch_bounds__(64 * WAVES) void conv_direct_kernel(const ConvArgs 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// "Window" variant (fp32, stride 1, output grid == input grid) on 16 x 16 x 4 MFMA tiles.
+//
+// In-kernel stamps on the kernel above (M = 1568, 3x3, K = 1152: 49 workgroups) showed two things: the 16-byte row-strided fragment
+// loads of a workgroup (~300 KB) queue behind ONE CU's texture addresser (wave 0 done after 4 us, the last wave after 9 us), and
+// even with every operand on chip the 576 32x32x2 MFMAs of a 32-pixel x 32-channel tile keep that CU busy for 4.4 us while 80 % of
+// the chip idles.  So this variant
+//   * works on 16-pixel x 16*TN-channel tiles (v_mfma_f32_16x16x4_f32): 4x as many workgroups, a quarter of the MFMA time each,
+//   * reads weights from a fragment-major mirror of the blob (LaunchPermuteWeightsFrag: one fragment load = 1 KiB contiguous),
+//   * copies the activations the 16 output pixels touch - ONE contiguous run of 16 + (kh-1)*W + (kw-1) NHWC pixel rows (taps are
+//     shifts of the flattened pixel index; rows that belong to the neighbouring line / image are masked per lane, which is exactly
+//     the padding rule) - to LDS with coalesced loads, BN+ReLU prologue applied on the way, and reads fragments from there.
+// K is still split over the waves and reduced through LDS in wave order (the partial tiles reuse the window's storage).
+// MFMA layout: D = W x A^T, lane (r, gk) supplies row r (an output channel resp. a pixel) and the 4 channels c0 + 4*gk + e, and ends
+// up with channels 4*gk .. 4*gk+3 of pixel r.
+// ------------------------------------------------------------------------------------------------------------------------
+template <int TN, int WAVES, int MAXC, bool PRE>
+__global__ __launch_bounds__(64 * WAVES) void conv_win_kernel(const ConvArgs a, const DirectGeom g) {
+    constexpr int NT = 64 * WAVES, BN = 16 * TN, PP = BN + 4;
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_direct[];
+    float* const sWin = reinterpret_cast<float*>(smem_direct);                     // [npx][P]
+    float* const sPart = reinterpret_cast<float*>(smem_direct);                    // [WAVES][16][PP], after the window is dead
+
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, gk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Cin = a.in.c, H = a.in.h, W = a.in.w, Cout = a.out.c;
+    const int P = Cin + 4;                             // rows 4 banks apart: the 16 rows of a quarter-wave cover all 64 banks
+    const int M = a.out.n * H * W;
+    const int m0 = blockIdx.x * 16, n0 = blockIdx.y * BN;
+    const int ipitch = int(a.in.sw);
+
+    // ---- this wave's weight fragments: fragment-major, 1 KiB per load, all in flight at once ----
+    const int cb = int(int64_t(g.total) * wave / WAVES), ce = int(int64_t(g.total) * (wave + 1) / WAVES);
+    const __amdgpu_buffer_rsrc_t rs_w =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wfrag), 0, Cout * a.kh * a.kw * Cin * 4, 0x00020000);
+    u32x4 B[MAXC][TN];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int ch = cb + i;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            B[i][j] = __builtin_amdgcn_raw_buffer_load_b128(
+                rs_w, ch < ce ? unsigned(((int(blockIdx.y) * TN + j) * g.total + ch) * 64 + lane) * 16u : OOB, 0, 0);
+    }
+
+    // ---- activation window -> LDS (coalesced rows; prologue applied here, padding is masked at fragment time) ----
+    {
+        constexpr int U = 4;
+        const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(a.in.p, 0, int(a.in_bytes), 0x00020000);
+        const int c4n = Cin >> 2;
+        const int p_lo = m0 - a.pt * W - a.pl;
+        const int npx = 16 + (a.kh - 1) * W + (a.kw - 1);
+        const int items = npx * c4n;
+        for (int idx0 = tid; idx0 < items; idx0 += U * NT) {
+            u32x4 v[U];
+            int row[U], c4[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = idx0 + u * NT;
+                row[u] = idx / c4n;
+                c4[u] = idx - row[u] * c4n;
+                const int p = p_lo + row[u];
+                v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (idx < items && p >= 0 && p < M) ? unsigned(p * ipitch + c4[u] * 4) * 4u : OOB, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (idx0 + u * NT < items) {
+                    f32x4 x = __builtin_bit_cast(f32x4, v[u]);
+                    if constexpr (PRE) {
+                        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.pre_scale + c4[u] * 4);
+                        const f32x4 sf = *reinterpret_cast<const f32x4*>(a.pre_shift + c4[u] * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float y = x[e] * sc[e] + sf[e];
+                            x[e] = a.pre_relu ? fmaxf(y, 0.f) : y;
+                        }
+                    }
+                    *reinterpret_cast<f32x4*>(sWin + row[u] * P + c4[u] * 4) = x;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // this lane's output pixel (same grid as the input)
+    const int m = m0 + r;
+    const bool mok = m < M;
+    const int rem = (mok ? m : 0) % (H * W);
+    const int oy = rem / W, ox = rem - oy * W;
+
+    f32x4 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        if (cb + i < ce) {                             // wave-uniform
+            const int ch = cb + i;
+            const int tap = ch / g.cpt, c0 = (ch - tap * g.cpt) * 16;
+            const int ky = tap / a.kw, kx = tap - ky * a.kw;
+            const bool ok = mok && unsigned(oy + ky - a.pt) < unsigned(H) && unsigned(ox + kx - a.pl) < unsigned(W);
+            f32x4 av = *reinterpret_cast<const f32x4*>(sWin + (r + ky * W + kx) * P + c0 + gk * 4);
+            if (!ok) av = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const f32x4 bv = __builtin_bit_cast(f32x4, B[i][j]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[e], av[e], acc[j], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();                                   // every wave is done with the window: its storage becomes the partial tiles
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4*>(sPart + (wave * 16 + r) * PP + j * 16 + 4 * gk) = acc[j];
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rs_out =
+        __builtin_amdgcn_make_buffer_rsrc(a.out.p, 0, int((int64_t(M - 1) * a.out.sw + Cout) * 4), 0x00020000);
+    for (int idx = tid; idx < 16 * (BN / 2); idx += NT) {
+        const int p = idx / (BN / 2), c2 = (idx - p * (BN / 2)) * 2;
+        f32x2 v = {0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            const f32x2 x = *reinterpret_cast<const f32x2*>(sPart + (w * 16 + p) * PP + c2);
+            v[0] += x[0];
+            v[1] += x[1];
+        }
+        const int n = n0 + c2;                         // Cout % BN == 0 (eligibility): always in range
+        if (a.bias != nullptr) { v[0] += a.bias[n]; v[1] += a.bias[n + 1]; }
+        if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); }
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, v), rs_out,
+                                              m0 + p < M ? unsigned((m0 + p) * int(a.out.sw) + n) * 4u : OOB, 0, 0);
+    }
+}
+
+// dst = fragment-major copy of one conv's weights [Cout][KK][Cin] (Cout % 16 == 0, Cin % 16 == 0): for 16-channel block nb, 16-channel
+// chunk ch = tap * (Cin/16) + c0/16, lane (gk, r): the 4 floats W[nb*16 + r][tap][c0 + 4gk .. +4)
+__global__ __launch_bounds__(256) void permute_weights_frag_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int KK, int Cin) {
+    const int cpt = Cin >> 4, total = KK * cpt;
+    const int64_t n4 = int64_t(Cout) * KK * Cin / 4;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n4; i += int64_t(gridDim.x) * 256) {
+        const int lane = int(i & 63);
+        const int64_t t = i >> 6;
+        const int ch = int(t % total), nb = int(t / total);
+        const int tap = ch / cpt, c0 = (ch - tap * cpt) * 16;
+        const int r = lane & 15, gk = lane >> 4;
+        reinterpret_cast<f32x4*>(dst)[i] = *reinterpret_cast<const f32x4*>(src + (int64_t(nb * 16 + r) * KK + tap) * Cin + c0 + gk * 4);
+    }
+}
+
+hipError_t LaunchPermuteWeightsFrag(const float* src, float* dst, int Cout, int KK, int Cin, hipStream_t stream) {
+    if ((Cout % 16) || (Cin % 16) || Cout <= 0 || KK <= 0) return hipErrorInvalidValue;
+    const int64_t n4 = int64_t(Cout) * KK * Cin / 4;
+    const unsigned blocks = unsigned(std::min<int64_t>((n4 + 255) / 256, 2048));
+    permute_weights_frag_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(src, dst, Cout, KK, Cin);
+    return hipGetLastError();
+}
+
+struct WinTile { int tn, waves, maxc; };
+constexpr int kNumWinTiles = kNumConvDirectTiles - kNumDirectBaseTiles;
+constexpr WinTile kWinTiles[kNumWinTiles] = {{1, 8, 9}, {2, 8, 9}, {1, 4, 18}, {2, 4, 18}};
+
+static size_t win_lds_bytes(const ConvArgs& a, const WinTile& t) {
+    const size_t win = size_t(16 + (a.kh - 1) * a.in.w + (a.kw - 1)) * (a.in.c + 4) * 4;
+    const size_t part = size_t(t.waves) * 16 * (16 * t.tn + 4) * 4;
+    return win > part ? win : part;
+}
+
+static bool win_eligible(const ConvArgs& a, int wt) {
+    const WinTile t = kWinTiles[wt];
+    if (a.in.f16 || a.out.f16 || a.wfrag == nullptr || a.res.p != nullptr) return false;
+    if (a.in.sc != 1 || a.out.sc != 1 || (a.in.c % 16) || (a.out.c % (16 * t.tn))) return false;
+    if (a.sh != 1 || a.sw != 1 || a.out.h != a.in.h || a.out.w != a.in.w || a.out.n != a.in.n) return false;
+    if (a.pt < 0 || a.pl < 0 || a.pt >= a.kh || a.pl >= a.kw) return false;
+    if ((a.in.sw % 4) || a.in.sh != a.in.w * a.in.sw || a.in.sn != a.in.h * a.in.sh || (reinterpret_cast<uintptr_t>(a.in.p) & 15)) return false;
+    if ((reinterpret_cast<uintptr_t>(a.wfrag) & 15) || (a.out.sw & 1) || (reinterpret_cast<uintptr_t>(a.out.p) & 7)) return false;
+    if (a.out.sh != a.out.w * a.out.sw || a.out.sn != a.out.h * a.out.sh) return false;
+    if (a.pre_scale && ((reinterpret_cast<uintptr_t>(a.pre_scale) & 15) || (reinterpret_cast<uintptr_t>(a.pre_shift) & 15))) return false;
+    const int64_t M = int64_t(a.out.n) * a.out.h * a.out.w;
+    if (M > 65536 || (M + 64) * a.in.sw * 4 >= (int64_t(1) << 31) || M * a.out.sw * 4 >= (int64_t(1) << 31) ||
+        int64_t(a.out.c) * a.kh * a.kw * a.in.c * 4 >= (int64_t(1) << 31))
+        return false;
+    const int total = a.kh * a.kw * (a.in.c / 16);
+    if (total > t.waves * t.maxc || total < t.waves) return false;
+    return win_lds_bytes(a, t) <= size_t(160) * 1024;
+}
+
+template <int WT>
+static hipError_t launch_win_t(const ConvArgs& a, hipStream_t stream) {
+    constexpr WinTile t = kWinTiles[WT];
+    DirectGeom g;
+    g.cpt = a.in.c / 16;
+    g.total = a.kh * a.kw * g.cpt;
+    const int64_t M = int64_t(a.out.n) * a.out.h * a.out.w;
+    const dim3 grid(unsigned((M + 15) / 16), unsigned(a.out.c / (16 * t.tn)));
+    const size_t lds = win_lds_bytes(a, t);
+    if (a.pre_scale) conv_win_kernel<t.tn, t.waves, t.maxc, true><<<grid, dim3(64 * t.waves), lds, stream>>>(a, g);
+    else conv_win_kernel<t.tn, t.waves, t.maxc, false><<<grid, dim3(64 * t.waves), lds, stream>>>(a, g);
+    return hipGetLastError();
+}
+
 struct DirectTile { int tn, waves, maxc; };
-constexpr DirectTile kDirectTiles[kNumConvDirectTiles] = {{1, 8, 8}, {1, 16, 4}, {1, 9, 8}, {1, 4, 8}, {1, 12, 6}, {2, 8, 4}};
+constexpr DirectTile kDirectTiles[kNumDirectBaseTiles] = {{1, 8, 8}, {1, 16, 4}, {1, 9, 8}, {1, 4, 8}, {1, 12, 6}, {2, 8, 4}};
 
 static size_t direct_lds_bytes(int tile, int Cin, bool half, bool pre) {
     const DirectTile t = kDirectTiles[tile];
@@ -206,6 +409,7 @@ static size_t direct_lds_bytes(int tile, int Cin, bool half, bool pre) {
 
 bool ConvDirectEligible(const ConvArgs& a, int tile) {
     if (tile < 0 || tile >= kNumConvDirectTiles) return false;
+    if (tile >= kNumDirectBaseTiles) return win_eligible(a, tile - kNumDirectBaseTiles);
     const bool half = a.in.f16 != 0;
     const int cw = half ? 32 : 16;
     if (a.in.sc != 1 || a.out.sc != 1 || (a.in.c % cw) || a.kh * a.kw > 49) return false;
@@ -253,6 +457,13 @@ hipError_t LaunchConvDirect(const ConvArgs& a_in, int tile, hipStream_t stream) 
     ConvArgs a = a_in;
     const int esz = a.in.f16 ? 2 : 4;
     a.in_bytes = esz * (int64_t(a.in.n - 1) * a.in.sn + int64_t(a.in.h - 1) * a.in.sh + int64_t(a.in.w - 1) * a.in.sw + int64_t(a.in.c - 1) + 1);
+    switch (tile - kNumDirectBaseTiles) {
+        case 0: return launch_win_t<0>(a, stream);
+        case 1: return launch_win_t<1>(a, stream);
+        case 2: return launch_win_t<2>(a, stream);
+        case 3: return launch_win_t<3>(a, stream);
+        default: break;
+    }
 #define IE_DIR(T) \
     case T: return a.in.f16 ? launch_direct_t<true, T>(a, stream) : launch_direct_t<false, T>(a, stream);
     switch (tile) {
@@ -272,8 +483,20 @@ static hipError_t init_direct_t() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
+template <int WT>
+static hipError_t init_win_t() {
+    constexpr WinTile t = kWinTiles[WT];
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_win_kernel<t.tn, t.waves, t.maxc, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_win_kernel<t.tn, t.waves, t.maxc, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
 hipError_t InitKernelsDirect() {
     hipError_t e;
+    if ((e = init_win_t<0>()) != hipSuccess) return e;
+    if ((e = init_win_t<1>()) != hipSuccess) return e;
+    if ((e = init_win_t<2>()) != hipSuccess) return e;
+    if ((e = init_win_t<3>()) != hipSuccess) return e;
 #define IE_DIRI(T)                                                     \
     if ((e = init_direct_t<false, T>()) != hipSuccess) return e;       \
     if ((e = init_direct_t<true, T>()) != hipSuccess) return e;

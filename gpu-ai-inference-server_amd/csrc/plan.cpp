@@ -805,8 +805,17 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                            pr3 <= ws3_cfg[t3][2] * (64 * ws3_cfg[t3][0] / 8) && (9 * ((s.in.c + 63) / 64) * 32 + pr3) * 144 + 128 <= 160 * 1024;
                 };
                 static const int dcfg[6][3] = {{1, 8, 8}, {1, 16, 4}, {1, 9, 8}, {1, 4, 8}, {1, 12, 6}, {2, 8, 4}};   // tn, waves, max chunks
+                static const int wcfg[4][3] = {{1, 8, 9}, {2, 8, 9}, {1, 4, 18}, {2, 4, 18}};                      // window variants: tn, waves, max chunks
                 auto direct_ok = [&](int t) {
-                    if (t < 0 || t >= 6) return false;
+                    if (t < 0 || t >= 10) return false;
+                    if (t >= 6) {      // fp32, output grid == input grid, activations through an LDS window, fragment-major weights
+                        const int* wc = wcfg[t - 6];
+                        const int64_t total = s.in.c % 16 == 0 ? int64_t(n.kh) * n.kw * (s.in.c / 16) : 0;
+                        const int64_t win = (16 + (n.kh - 1) * s.in.w + (n.kw - 1)) * (s.in.c + 4) * 4, part = int64_t(wc[1]) * 16 * (16 * wc[0] + 4) * 4;
+                        return vec_ok && !in16 && !s.out.f16 && !s.has_in2 && s.in.c % 16 == 0 && N % (16 * wc[0]) == 0 && n.sh == 1 && n.sw == 1 &&
+                               s.out.h == s.in.h && s.out.w == s.in.w && n.pt < n.kh && n.pl < n.kw && s.out.pitch % 2 == 0 && s.out.c_off % 2 == 0 &&
+                               total >= wc[1] && total <= wc[1] * wc[2] && M <= 65536 && n.kh * n.kw <= 49 && std::max(win, part) <= 160 * 1024;
+                    }
                     const int cw = in16 ? 32 : 16, al = in16 ? 8 : 4;
                     const int64_t total = s.in.c % cw == 0 ? int64_t(n.kh) * n.kw * (s.in.c / cw) : 0;
                     return (vec_ok || vec16_ok) && s.in.c % cw == 0 && s.in.pitch % al == 0 && s.in.c_off % al == 0 && N % 2 == 0 && s.out.pitch % 2 == 0 &&
@@ -819,6 +828,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                 if (!std::getenv("IE_FORCE_ALGO") && !std::getenv("IE_FORCE_TILE") && s.algo == ConvAlgo::IgemmVec) {
                     int pick = -1;
                     if (M <= 2048) {                                                       // tiny grids: split K over the waves
+                        if (is3x3 && direct_ok(6)) pick = 6;                             // 16-pixel window tiles: 4x the workgroups
                         for (int t : {1, 0, 4, 3}) if (pick < 0 && direct_ok(t)) pick = t;
                         if (pick >= 0) { s.algo = ConvAlgo::Direct; s.tile = pick; }
                     } else if (in16) {
@@ -847,7 +857,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                     }
                     else if (f == "direct") {
                         int t = 0;
-                        if (const char* ft = std::getenv("IE_FORCE_TILE")) { int v = std::atoi(ft); if (v >= 0 && v < 6) t = v; }
+                        if (const char* ft = std::getenv("IE_FORCE_TILE")) { int v = std::atoi(ft); if (v >= 0 && v < 10) t = v; }
                         if (direct_ok(t)) { s.algo = ConvAlgo::Direct; s.tile = t; }
                         else if (s.algo == ConvAlgo::Naive && (vec_ok || vec16_ok)) s.algo = ConvAlgo::IgemmVec;
                     }

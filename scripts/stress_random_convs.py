@@ -22,7 +22,7 @@ count = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 modes32 = [dict(), dict(IE_AUTOTUNE="0"), dict(IE_FORCE_ALGO="raster"), dict(IE_FORCE_ALGO="igemm", IE_FORCE_TILE="8"),
            dict(IE_FORCE_ALGO="scalar"), dict(IE_FORCE_ALGO="igemm", IE_FORCE_SPLITK="3", IE_FORCE_TILE="3"),
            dict(IE_FORCE_ALGO="ws", IE_FORCE_TILE="2"), dict(IE_FORCE_ALGO="ws", IE_FORCE_TILE="12"), dict(IE_FORCE_ALGO="direct", IE_FORCE_TILE="0"),
-           dict(IE_FORCE_ALGO="direct", IE_FORCE_TILE="4")]
+           dict(IE_FORCE_ALGO="direct", IE_FORCE_TILE="4"), dict(IE_FORCE_ALGO="direct", IE_FORCE_TILE="6"), dict(IE_FORCE_ALGO="direct", IE_FORCE_TILE="9")]
 modes16 = [dict(), dict(IE_AUTOTUNE="0"), dict(IE_FORCE_ALGO="igemm", IE_FORCE_TILE="9"), dict(IE_FORCE_ALGO="ws", IE_FORCE_TILE="0"),
            dict(IE_FORCE_ALGO="ws", IE_FORCE_TILE="5"), dict(IE_FORCE_ALGO="direct", IE_FORCE_TILE="1"), dict(IE_FORCE_ALGO="naive")]
 worst = {"fp32": 0.0, "fp16": 0.0}

@@ -570,6 +570,77 @@ def test_direct_split_k_kernel(tmp_path, tile, prec):
     assert e < (RTOL if prec == "fp32" else F16_RTOL), (tile, prec, e)
 
 
+@pytest.mark.parametrize("tile", [6, 7, 8, 9])
+def test_direct_window_kernel(tmp_path, tile):
+    """conv_win_kernel (direct tiles 6-9, fp32, 16x16x4 MFMA tiles): activations of a 16-pixel row block copied once into an LDS
+    window (ragged last block, blocks that straddle two images), weights read from the fragment-major mirror, 16 / 32 output channels
+    per workgroup, K split over 8 / 4 waves - 1x1 convs with the BN+ReLU prologue reading a slice of the concat buffer and 3x3 convs
+    with zero padding."""
+    mb = models.densenet(3, growth=32, blocks=(3, 3), stem=256, image=56, classes=24, seed=83)
+    path = models.write_repo(str(tmp_path), "win", mb)
+    om = O.load_model(mb)
+    x = models.synthetic_input((3, 3, 56, 56), stream="win")
+    ref = O.run(om, {"data_0": x}, dtype=np.float64)["fc6_1"]
+
+    def go():
+        plan = B.DescribeModel(path, 3)["plan"]
+        nd = sum(1 for st in plan["steps"] if st.get("algo") == "direct")
+        m = B.CreateModel(path, "win")
+        try:
+            y, _ = infer(m, "", "data_0", x, "fc6_1", [3, 24, 1, 1])
+            y2, _ = infer(m, "", "data_0", x, "fc6_1", [3, 24, 1, 1])
+            prof = {p_["kernel"] for p_ in B.Profile(m, 1)}
+        finally:
+            m.Destroy()
+        return nd, y, y2, prof
+    nd, y, y2, prof = _run_with_env(dict(IE_FORCE_ALGO="direct", IE_FORCE_TILE=str(tile)), go)
+    np.testing.assert_array_equal(y, y2)
+    e = rel_err(y, ref)
+    print(f"direct window tile {tile}: {nd} convs, kernels {sorted(prof)}, rel err {e:.2e}")
+    assert nd >= 6, nd
+    assert f"conv_direct_kernel<f32,t{tile}>" in prof, prof        # ran on the window kernel, not on the implicit-GEMM fallback
+    assert e < RTOL, (tile, e)
+
+
+def test_window_kernel_random_same_size_convs(tmp_path):
+    """Random stride-1 'same' convolutions (k = 1/3/5, 16-aligned Cin, Cout % 16 == 0, ragged pixel counts, prologue / bias / epilogue
+    variants, channel-offset stores into the Concat buffer) on the window kernel vs the float64 oracle."""
+    rs = np.random.RandomState(4242)
+    done, worst = 0, 0.0
+    for case in range(400):
+        mb, ishape, oshape, desc = _random_conv_graph(rs, case, cin_choices=(16, 32, 48, 64, 128))
+        if not (desc["stride"] == 1 and desc["pad"] == desc["k"] // 2 and desc["cout"] % 16 == 0 and desc["k"] <= 5):
+            continue
+        total = desc["k"] ** 2 * desc["cin"] // 16
+        ok = [t for t, (tn, wv, mc) in ((6, (1, 8, 9)), (7, (2, 8, 9)), (8, (1, 4, 18)), (9, (2, 4, 18)))
+              if wv <= total <= wv * mc and desc["cout"] % (16 * tn) == 0]
+        if not ok:
+            continue
+        tile = ok[case % len(ok)]
+        d = models.write_repo(str(tmp_path), f"w{case}", mb)
+        x = rs.rand(*ishape).astype(np.float32)
+        ref = O.run(O.load_model(mb), {"x": x}, dtype=np.float64)["out"]
+
+        def go():
+            m = B.CreateModel(d, "w")
+            try:
+                y, dims = infer(m, "", "x", x, "out", oshape)
+                kern = {p_["kernel"] for p_ in B.Profile(m, 1)}
+            finally:
+                m.Destroy()
+            return y, dims, kern
+        y, dims, kern = _run_with_env(dict(IE_FORCE_ALGO="direct", IE_FORCE_TILE=str(tile)), go)
+        assert f"conv_direct_kernel<f32,t{tile}>" in kern, (desc, kern)
+        e = rel_err(y, ref)
+        worst = max(worst, e)
+        assert dims == list(oshape) and e < RTOL, (desc, tile, e)
+        done += 1
+        if done >= 16:
+            break
+    print(f"window kernel: {done} random same-size convs, worst rel err {worst:.2e}")
+    assert done >= 10
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # fp16 precision mode (BASELINE.json configs[2-3]).  The reference never runs fp16 (its ONNX Runtime session computes the
 # model's own fp32), so there is no reference-side number to pin: "parity unpinned".  The checker is the float64 oracle /

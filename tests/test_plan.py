@@ -144,6 +144,11 @@ def test_forced_algorithms_respect_eligibility(densenet_repo, monkeypatch):
     p = B.DescribeModel(path, 32)["plan"]
     d = [s for s in p["steps"] if s.get("algo") == "direct"]
     assert d and all(8 <= s["k"][0] * s["k"][1] * s["in"]["c"] // 16 <= 64 and s["out"]["n"] * s["out"]["h"] * s["out"]["w"] <= 65536 for s in d)
+    monkeypatch.setenv("IE_FORCE_TILE", "6")          # window variant: 8 waves x up to 9 chunks, stride 1, output grid == input grid
+    p = B.DescribeModel(path, 32)["plan"]
+    d = [s for s in p["steps"] if s.get("algo") == "direct"]
+    assert len(d) >= 40 and all(8 <= s["k"][0] * s["k"][1] * s["in"]["c"] // 16 <= 72 and s["out"]["c"] % 16 == 0 and s["stride"] == [1, 1] and
+                                (s["out"]["h"], s["out"]["w"]) == (s["in"]["h"], s["in"]["w"]) for s in d)
 
 
 def test_resnet50_plan_fuses_shortcuts(tmp_path):
