@@ -357,7 +357,7 @@ hipError_t LaunchPermuteWeightsFrag(const float* src, float* dst, int Cout, int 
 }
 
 struct WinTile { int tn, waves, maxc; };
-constexpr int kNumWinTiles = kNumConvDirectTiles - kNumDirectBaseTiles;
+constexpr int kNumWinTiles = 4;
 constexpr WinTile kWinTiles[kNumWinTiles] = {{1, 8, 9}, {2, 8, 9}, {1, 4, 18}, {2, 4, 18}};
 
 static size_t win_lds_bytes(const ConvArgs& a, const WinTile& t) {
@@ -399,6 +399,178 @@ static hipError_t launch_win_t(const ConvArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// "Activations-stationary" 1x1 conv (fp32; direct tiles 10..12) for mid-size pixel counts with long K (DenseNet block 3 at batch
+// 32: M = 6272, N = 128, K = 256..992).  The tiled implicit GEMM has one 64 x 64 workgroup per CU there and pays an LDS round trip
+// + barrier per K tile with nothing to overlap it (16-31 us against an MFMA floor of 4-15 us); the weight slice [128][K] does not fit
+// in LDS, so the weights-stationary kernel does not apply.  Roles swapped: a workgroup copies ITS 32 pixels' K channels into LDS once
+// (coalesced rows, BN+ReLU prologue on the way; one barrier), every wave owns 16*TNW output channels and streams their weights
+// from the fragment-major mirror (1 KiB contiguous per load) through a register ring with static slots - no barrier and no LDS
+// write in the K loop.  16x16x4 MFMAs, two 16-pixel blocks per wave share each weight fragment; a lane ends up with 4 consecutive
+// channels of one pixel and stores them as one 16-byte quad.  Loads past the last chunk use an out-of-range offset (no traffic); the
+// last K % (16 * D) channels run from their ring slots behind wave-uniform branches.
+// ------------------------------------------------------------------------------------------------------------------------
+template <int WAVES, int TNW, bool PRE>
+__global__ __launch_bounds__(64 * WAVES) void conv1x1_as_kernel(const ConvArgs a) {
+    constexpr int NT = 64 * WAVES, D = 8, BNW = 16 * TNW, BN = BNW * WAVES;
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_direct[];
+    float* const sA = reinterpret_cast<float*>(smem_direct);                       // [32][P]
+
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, gk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K = a.in.c, P = K + 4, CH = K >> 4, Cout = a.out.c;
+    const int M = a.out.n * a.out.h * a.out.w;
+    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * BN + wave * BNW;
+    const int ipitch = int(a.in.sw), opitch = int(a.out.sw);
+
+    // ---- weight ring: chunk c of 16-channel block nb is the KiB at ((nb * CH + c) * 64 + lane) * 16 ----
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wfrag), 0, Cout * K * 4, 0x00020000);
+    const int nb = n0 >> 4;
+    u32x4 ring[D][TNW];
+    int c_l = 0;
+    auto issue = [&](int slot) {
+#pragma unroll
+        for (int j = 0; j < TNW; ++j)
+            ring[slot][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, c_l < CH ? unsigned(((nb + j) * CH + c_l) * 64 + lane) * 16u : OOB, 0, 0);
+        ++c_l;
+    };
+#pragma unroll
+    for (int s = 0; s < D; ++s) issue(s);
+
+    // ---- this workgroup's 32 pixel rows -> LDS ----
+    {
+        constexpr int U = 4;
+        const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(a.in.p, 0, int(a.in_bytes), 0x00020000);
+        const int c4n = K >> 2;
+        const int items = 32 * c4n;
+        for (int idx0 = tid; idx0 < items; idx0 += U * NT) {
+            u32x4 v[U];
+            int row[U], c4[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = idx0 + u * NT;
+                row[u] = idx / c4n;
+                c4[u] = idx - row[u] * c4n;
+                const int p = m0 + row[u];
+                v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (idx < items && p < M) ? unsigned(p * ipitch + c4[u] * 4) * 4u : OOB, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (idx0 + u * NT < items) {
+                    f32x4 x = __builtin_bit_cast(f32x4, v[u]);
+                    if constexpr (PRE) {
+                        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.pre_scale + c4[u] * 4);
+                        const f32x4 sf = *reinterpret_cast<const f32x4*>(a.pre_shift + c4[u] * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float y = x[e] * sc[e] + sf[e];
+                            x[e] = a.pre_relu ? fmaxf(y, 0.f) : y;
+                        }
+                    }
+                    *reinterpret_cast<f32x4*>(sA + row[u] * P + c4[u] * 4) = x;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    f32x4 acc[2][TNW];
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) acc[pb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int c_c = 0;
+    const float* const arow = sA + r * P + gk * 4;
+    auto compute = [&](int slot) {
+        const float* const src = arow + c_c * 16;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(src);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(src + 16 * P);
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) {
+            const f32x4 bv = __builtin_bit_cast(f32x4, ring[slot][j]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[e], a0[e], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[e], a1[e], acc[1][j], 0, 0, 0);
+            }
+        }
+        ++c_c;
+    };
+    const int full = CH / D, rem = CH - full * D;
+    for (int it = 0; it < full; ++it) {
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+            compute(s);
+            issue(s);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+        if (s < rem) compute(s);                       // wave-uniform: the last CH % D chunks are already in their slots
+
+    const __amdgpu_buffer_rsrc_t rs_out =
+        __builtin_amdgcn_make_buffer_rsrc(a.out.p, 0, int((int64_t(M - 1) * opitch + Cout) * 4), 0x00020000);
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+        const int m = m0 + pb * 16 + r;
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) {
+            const int n = n0 + j * 16 + 4 * gk;
+            f32x4 v = acc[pb][j];
+            if (a.bias != nullptr) {
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += bq[e];
+            }
+            if (a.relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_out, m < M ? unsigned(m * opitch + n) * 4u : OOB, 0, 0);
+        }
+    }
+}
+
+struct AsTile { int waves, tnw; };
+constexpr int kNumAsTiles = 3;
+constexpr AsTile kAsTiles[kNumAsTiles] = {{8, 1}, {4, 1}, {8, 2}};
+
+static bool as_eligible(const ConvArgs& a, int at) {
+    const AsTile t = kAsTiles[at];
+    if (a.in.f16 || a.out.f16 || a.wfrag == nullptr || a.res.p != nullptr) return false;
+    if (a.kh != 1 || a.kw != 1 || a.sh != 1 || a.sw != 1 || a.pt != 0 || a.pl != 0) return false;
+    if (a.out.h != a.in.h || a.out.w != a.in.w || a.out.n != a.in.n) return false;
+    if (a.in.sc != 1 || a.out.sc != 1 || (a.in.c % 16) || (a.out.c % (16 * t.tnw * t.waves))) return false;
+    if ((a.in.sw % 4) || a.in.sh != a.in.w * a.in.sw || a.in.sn != a.in.h * a.in.sh || (reinterpret_cast<uintptr_t>(a.in.p) & 15)) return false;
+    if ((a.out.sw % 4) || a.out.sh != a.out.w * a.out.sw || a.out.sn != a.out.h * a.out.sh || (reinterpret_cast<uintptr_t>(a.out.p) & 15)) return false;
+    if ((reinterpret_cast<uintptr_t>(a.wfrag) & 15) || (a.bias && (reinterpret_cast<uintptr_t>(a.bias) & 15))) return false;
+    if (a.pre_scale && ((reinterpret_cast<uintptr_t>(a.pre_scale) & 15) || (reinterpret_cast<uintptr_t>(a.pre_shift) & 15))) return false;
+    const int64_t M = int64_t(a.out.n) * a.out.h * a.out.w;
+    if (M > 65536 || M * a.in.sw * 4 >= (int64_t(1) << 31) || M * a.out.sw * 4 >= (int64_t(1) << 31) || int64_t(a.out.c) * a.in.c * 4 >= (int64_t(1) << 31))
+        return false;
+    return size_t(32) * (a.in.c + 4) * 4 <= size_t(160) * 1024;
+}
+
+template <int AT>
+static hipError_t launch_as_t(const ConvArgs& a, hipStream_t stream) {
+    constexpr AsTile t = kAsTiles[AT];
+    const int64_t M = int64_t(a.out.n) * a.out.h * a.out.w;
+    const dim3 grid(unsigned((M + 31) / 32), unsigned(a.out.c / (16 * t.tnw * t.waves)));
+    const size_t lds = size_t(32) * (a.in.c + 4) * 4;
+    if (a.pre_scale) conv1x1_as_kernel<t.waves, t.tnw, true><<<grid, dim3(64 * t.waves), lds, stream>>>(a);
+    else conv1x1_as_kernel<t.waves, t.tnw, false><<<grid, dim3(64 * t.waves), lds, stream>>>(a);
+    return hipGetLastError();
+}
+
+template <int AT>
+static hipError_t init_as_t() {
+    constexpr AsTile t = kAsTiles[AT];
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_as_kernel<t.waves, t.tnw, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_as_kernel<t.waves, t.tnw, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
 struct DirectTile { int tn, waves, maxc; };
 constexpr DirectTile kDirectTiles[kNumDirectBaseTiles] = {{1, 8, 8}, {1, 16, 4}, {1, 9, 8}, {1, 4, 8}, {1, 12, 6}, {2, 8, 4}};
 
@@ -409,6 +581,7 @@ static size_t direct_lds_bytes(int tile, int Cin, bool half, bool pre) {
 
 bool ConvDirectEligible(const ConvArgs& a, int tile) {
     if (tile < 0 || tile >= kNumConvDirectTiles) return false;
+    if (tile >= kNumDirectBaseTiles + kNumWinTiles) return as_eligible(a, tile - kNumDirectBaseTiles - kNumWinTiles);
     if (tile >= kNumDirectBaseTiles) return win_eligible(a, tile - kNumDirectBaseTiles);
     const bool half = a.in.f16 != 0;
     const int cw = half ? 32 : 16;
@@ -462,6 +635,9 @@ hipError_t LaunchConvDirect(const ConvArgs& a_in, int tile, hipStream_t stream) 
         case 1: return launch_win_t<1>(a, stream);
         case 2: return launch_win_t<2>(a, stream);
         case 3: return launch_win_t<3>(a, stream);
+        case 4: return launch_as_t<0>(a, stream);
+        case 5: return launch_as_t<1>(a, stream);
+        case 6: return launch_as_t<2>(a, stream);
         default: break;
     }
 #define IE_DIR(T) \
@@ -497,6 +673,9 @@ hipError_t InitKernelsDirect() {
     if ((e = init_win_t<1>()) != hipSuccess) return e;
     if ((e = init_win_t<2>()) != hipSuccess) return e;
     if ((e = init_win_t<3>()) != hipSuccess) return e;
+    if ((e = init_as_t<0>()) != hipSuccess) return e;
+    if ((e = init_as_t<1>()) != hipSuccess) return e;
+    if ((e = init_as_t<2>()) != hipSuccess) return e;
 #define IE_DIRI(T)                                                     \
     if ((e = init_direct_t<false, T>()) != hipSuccess) return e;       \
     if ((e = init_direct_t<true, T>()) != hipSuccess) return e;

@@ -641,6 +641,80 @@ def test_window_kernel_random_same_size_convs(tmp_path):
     assert done >= 10
 
 
+def _pointwise_graph(rs, n, h, w, cin, cout, pre, bias, relu):
+    """x -> 1x1 conv (3 -> cin, moves the tensor into NHWC) -> [BN + ReLU] -> 1x1 conv (cin -> cout) [+ bias] [-> ReLU]."""
+    from gpu_ai_inference_server_amd.modelgen import onnx_pb as pb
+    nodes, inits = [], []
+    inits.append(pb.tensor("w0", (rs.randn(cin, 3, 1, 1) * 0.5).astype(np.float32)))
+    nodes.append(pb.node("Conv", ["x", "w0"], ["h0"], "c0", [pb.attr_ints("kernel_shape", [1, 1])]))
+    x = "h0"
+    if pre:
+        for nm, v in (("g", 1 + 0.1 * rs.randn(cin)), ("b", 0.1 * rs.randn(cin)), ("m", 0.1 * rs.randn(cin)), ("v", 0.5 + rs.rand(cin))):
+            inits.append(pb.tensor("pre_" + nm, v.astype(np.float32)))
+        nodes.append(pb.node("BatchNormalization", [x, "pre_g", "pre_b", "pre_m", "pre_v"], ["p0"], "prebn", [pb.attr_float("epsilon", 1e-5)]))
+        nodes.append(pb.node("Relu", ["p0"], ["p1"], "prerelu"))
+        x = "p1"
+    inits.append(pb.tensor("w", (rs.randn(cout, cin, 1, 1) * np.sqrt(2.0 / cin)).astype(np.float32)))
+    ins = [x, "w"]
+    if bias:
+        inits.append(pb.tensor("bvec", (0.2 * rs.randn(cout)).astype(np.float32)))
+        ins.append("bvec")
+    nodes.append(pb.node("Conv", ins, ["y0" if relu else "out"], "conv", [pb.attr_ints("kernel_shape", [1, 1])]))
+    if relu:
+        nodes.append(pb.node("Relu", ["y0"], ["out"], "postrelu"))
+    g = pb.graph("pointwise", nodes, inits, [pb.value_info("x", [n, 3, h, w])], [pb.value_info("out", [n, cout, h, w])])
+    return pb.model(g)
+
+
+@pytest.mark.parametrize("tile", [10, 11, 12])
+def test_activations_stationary_1x1_kernel(tmp_path, tile):
+    """conv1x1_as_kernel (direct tiles 10-12, fp32): the workgroup's 32 pixel rows staged once in LDS, weights streamed from the
+    fragment-major mirror through a register ring - K from 16 (shorter than the ring) to 1008 (not a multiple of the ring depth),
+    ragged last row block, prologue / bias / ReLU variants, 128 / 64 / 256 output channels per workgroup; plus the mini DenseNet."""
+    rs = np.random.RandomState(500 + tile)
+    per_wg = {10: 128, 11: 64, 12: 256}[tile]
+    worst = 0.0
+    for case, (n, h, w, cin) in enumerate([(1, 5, 7, 16), (2, 9, 9, 48), (3, 14, 14, 256), (2, 7, 13, 1008), (5, 6, 6, 144), (1, 12, 11, 400)]):
+        cout = per_wg * (1 + case % 2)
+        mb = _pointwise_graph(rs, n, h, w, cin, cout, pre=case % 3 != 0, bias=case % 2 == 0, relu=case % 4 != 1)
+        d = models.write_repo(str(tmp_path), f"as{tile}_{case}", mb)
+        x = rs.rand(n, 3, h, w).astype(np.float32)
+        ref = O.run(O.load_model(mb), {"x": x}, dtype=np.float64)["out"]
+
+        def go():
+            m = B.CreateModel(d, "as")
+            try:
+                y, dims = infer(m, "", "x", x, "out", (n, cout, h, w))
+                kern = {p_["kernel"] for p_ in B.Profile(m, 1)}
+            finally:
+                m.Destroy()
+            return y, dims, kern
+        y, dims, kern = _run_with_env(dict(IE_FORCE_ALGO="direct", IE_FORCE_TILE=str(tile)), go)
+        assert f"conv_direct_kernel<f32,t{tile}>" in kern, (case, kern)
+        e = rel_err(y, ref)
+        worst = max(worst, e)
+        assert dims == [n, cout, h, w] and e < RTOL, (tile, case, e)
+    if tile != 12:
+        mb = models.densenet(3, growth=32, blocks=(3, 3), stem=256, image=56, classes=24, seed=87)
+        path = models.write_repo(str(tmp_path), "asnet", mb)
+        x = models.synthetic_input((3, 3, 56, 56), stream="as")
+        ref = O.run(O.load_model(mb), {"data_0": x}, dtype=np.float64)["fc6_1"]
+
+        def go_net():
+            m = B.CreateModel(path, "asnet")
+            try:
+                y, _ = infer(m, "", "data_0", x, "fc6_1", [3, 24, 1, 1])
+                kern = {p_["kernel"] for p_ in B.Profile(m, 1)}
+            finally:
+                m.Destroy()
+            return y, kern
+        y, kern = _run_with_env(dict(IE_FORCE_ALGO="direct", IE_FORCE_TILE=str(tile)), go_net)
+        assert f"conv_direct_kernel<f32,t{tile}>" in kern, kern       # the bottleneck 1x1s read a slice of the concat buffer
+        worst = max(worst, rel_err(y, ref))
+        assert rel_err(y, ref) < RTOL
+    print(f"activations-stationary tile {tile}: worst rel err {worst:.2e}")
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # fp16 precision mode (BASELINE.json configs[2-3]).  The reference never runs fp16 (its ONNX Runtime session computes the
 # model's own fp32), so there is no reference-side number to pin: "parity unpinned".  The checker is the float64 oracle /
