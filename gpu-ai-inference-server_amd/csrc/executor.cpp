@@ -438,8 +438,9 @@ void DeviceModel::Autotune(PlanInstance& pi) {
                     }
                 }
             }
-            // small output grids: K split over the waves of a workgroup, operands straight from global memory
-            if (s.algo == ConvAlgo::IgemmVec && M <= 65536) {
+            // the kernels_direct.hip family (every variant checks its own pixel-count / shape limits): K split over the waves with
+            // operands straight from global memory, LDS-window tiles, activations-stationary 1x1, window + streamed weights
+            if (s.algo == ConvAlgo::IgemmVec) {
                 ConvArgs probe = MakeConvArgs(pi, s);
                 for (int t = 0; t < kNumConvDirectTiles; ++t) {
                     if (!ConvDirectEligible(probe, t)) continue;
