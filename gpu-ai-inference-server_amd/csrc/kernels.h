@@ -94,8 +94,8 @@ hipError_t InitKernelsWs3();
 // "Direct split-K" conv for small output grids (kernels_direct.hip): K split over the waves of a workgroup, both operands loaded
 // straight from global memory into MFMA fragments (all at once), partial tiles summed through LDS.  fp32 and fp16.
 constexpr int kNumDirectBaseTiles = 6;     // tiles 0..5: both operands straight from global memory
-constexpr int kNumConvDirectTiles = 13;    // tiles 6..9: "window" variants (fp32, 16x16x4 MFMA tiles): activations through LDS, fragment-major weights
-                                           // tiles 10..12: activations-stationary 1x1 (fp32): 32 pixel rows in LDS, weights streamed from the mirror
+constexpr int kNumConvDirectTiles = 15;    // tiles 6..9: "window" variants (fp32, 16x16x4 MFMA tiles): activations through LDS, fragment-major weights
+                                           // tiles 10..14: activations-stationary 1x1 (fp32): 32 / 16 pixel rows in LDS, weights streamed from the mirror
 hipError_t LaunchPermuteWeightsFrag(const float* src, float* dst, int Cout, int KK, int Cin, hipStream_t stream);
 bool ConvDirectEligible(const ConvArgs& a, int tile);
 hipError_t LaunchConvDirect(const ConvArgs& a, int tile, hipStream_t stream);

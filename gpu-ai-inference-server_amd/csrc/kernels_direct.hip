@@ -403,25 +403,25 @@ static hipError_t launch_win_t(const ConvArgs& a, hipStream_t stream) {
 // "Activations-stationary" 1x1 conv (fp32; direct tiles 10..12) for mid-size pixel counts with long K (DenseNet block 3 at batch
 // 32: M = 6272, N = 128, K = 256..992).  The tiled implicit GEMM has one 64 x 64 workgroup per CU there and pays an LDS round trip
 // + barrier per K tile with nothing to overlap it (16-31 us against an MFMA floor of 4-15 us); the weight slice [128][K] does not fit
-// in LDS, so the weights-stationary kernel does not apply.  Roles swapped: a workgroup copies ITS 32 pixels' K channels into LDS once
+// in LDS, so the weights-stationary kernel does not apply.  Roles swapped: a workgroup copies ITS 32 (16) pixels' K channels into LDS once
 // (coalesced rows, BN+ReLU prologue on the way; one barrier), every wave owns 16*TNW output channels and streams their weights
 // from the fragment-major mirror (1 KiB contiguous per load) through a register ring with static slots - no barrier and no LDS
 // write in the K loop.  16x16x4 MFMAs, two 16-pixel blocks per wave share each weight fragment; a lane ends up with 4 consecutive
 // channels of one pixel and stores them as one 16-byte quad.  Loads past the last chunk use an out-of-range offset (no traffic); the
 // last K % (16 * D) channels run from their ring slots behind wave-uniform branches.
 // ------------------------------------------------------------------------------------------------------------------------
-template <int WAVES, int TNW, bool PRE>
+template <int WAVES, int TNW, int PB, bool PRE>
 __global__ __launch_bounds__(64 * WAVES) void conv1x1_as_kernel(const ConvArgs a) {
-    constexpr int NT = 64 * WAVES, D = 8, BNW = 16 * TNW, BN = BNW * WAVES;
+    constexpr int NT = 64 * WAVES, D = PB == 1 ? 16 : 8, BNW = 16 * TNW, BN = BNW * WAVES;      // 16-pixel tiles: 128 MFMA cycles per chunk need a deeper ring to cover the weight latency
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_direct[];
-    float* const sA = reinterpret_cast<float*>(smem_direct);                       // [32][P]
+    float* const sA = reinterpret_cast<float*>(smem_direct);                       // [16 * PB][P]
 
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, gk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int K = a.in.c, P = K + 4, CH = K >> 4, Cout = a.out.c;
     const int M = a.out.n * a.out.h * a.out.w;
-    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * BN + wave * BNW;
+    const int m0 = blockIdx.x * (16 * PB), n0 = blockIdx.y * BN + wave * BNW;
     const int ipitch = int(a.in.sw), opitch = int(a.out.sw);
 
     // ---- weight ring: chunk c of 16-channel block nb is the KiB at ((nb * CH + c) * 64 + lane) * 16 ----
@@ -438,12 +438,12 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_as_kernel(const ConvArgs a
 #pragma unroll
     for (int s = 0; s < D; ++s) issue(s);
 
-    // ---- this workgroup's 32 pixel rows -> LDS ----
+    // ---- this workgroup's 16 * PB pixel rows -> LDS ----
     {
         constexpr int U = 4;
         const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(a.in.p, 0, int(a.in_bytes), 0x00020000);
         const int c4n = K >> 2;
-        const int items = 32 * c4n;
+        const int items = 16 * PB * c4n;
         for (int idx0 = tid; idx0 < items; idx0 += U * NT) {
             u32x4 v[U];
             int row[U], c4[U];
@@ -475,26 +475,34 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_as_kernel(const ConvArgs a
     }
     __syncthreads();
 
-    f32x4 acc[2][TNW];
+    f32x4 acc[PB][TNW];
 #pragma unroll
-    for (int pb = 0; pb < 2; ++pb)
+    for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
         for (int j = 0; j < TNW; ++j) acc[pb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     int c_c = 0;
     const float* const arow = sA + r * P + gk * 4;
+    // activation fragments are read one chunk ahead of the MFMAs that consume them (the LDS latency hides behind 4*PB*TNW MFMAs
+    // instead of stalling every chunk; the scheduler otherwise sinks each read to its use)
+    f32x4 avn[PB];
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) avn[pb] = *reinterpret_cast<const f32x4*>(arow + pb * 16 * P);
     auto compute = [&](int slot) {
-        const float* const src = arow + c_c * 16;
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(src);
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(src + 16 * P);
+        f32x4 av[PB];
 #pragma unroll
-        for (int j = 0; j < TNW; ++j) {
-            const f32x4 bv = __builtin_bit_cast(f32x4, ring[slot][j]);
+        for (int pb = 0; pb < PB; ++pb) av[pb] = avn[pb];
+        const float* const nxt = arow + (c_c + 1 < CH ? c_c + 1 : c_c) * 16;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[e], a0[e], acc[0][j], 0, 0, 0);
-                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[e], a1[e], acc[1][j], 0, 0, 0);
-            }
-        }
+        for (int pb = 0; pb < PB; ++pb) avn[pb] = *reinterpret_cast<const f32x4*>(nxt + pb * 16 * P);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int j = 0; j < TNW; ++j)
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb)
+                    acc[pb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(f32x4, ring[slot][j])[e], av[pb][e], acc[pb][j], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, PB, 0);                 // next chunk's fragment reads first ...
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * PB * TNW, 0);       // ... then this chunk's MFMAs
         ++c_c;
     };
     const int full = CH / D, rem = CH - full * D;
@@ -512,7 +520,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_as_kernel(const ConvArgs a
     const __amdgpu_buffer_rsrc_t rs_out =
         __builtin_amdgcn_make_buffer_rsrc(a.out.p, 0, int((int64_t(M - 1) * opitch + Cout) * 4), 0x00020000);
 #pragma unroll
-    for (int pb = 0; pb < 2; ++pb) {
+    for (int pb = 0; pb < PB; ++pb) {
         const int m = m0 + pb * 16 + r;
 #pragma unroll
         for (int j = 0; j < TNW; ++j) {
@@ -532,9 +540,9 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_as_kernel(const ConvArgs a
     }
 }
 
-struct AsTile { int waves, tnw; };
-constexpr int kNumAsTiles = 3;
-constexpr AsTile kAsTiles[kNumAsTiles] = {{8, 1}, {4, 1}, {8, 2}};
+struct AsTile { int waves, tnw, pb; };
+constexpr int kNumAsTiles = 5;
+constexpr AsTile kAsTiles[kNumAsTiles] = {{8, 1, 2}, {4, 1, 2}, {8, 2, 2}, {4, 1, 1}, {2, 2, 1}};      // the 16-pixel tiles: the smallest grids
 
 static bool as_eligible(const ConvArgs& a, int at) {
     const AsTile t = kAsTiles[at];
@@ -549,26 +557,26 @@ static bool as_eligible(const ConvArgs& a, int at) {
     const int64_t M = int64_t(a.out.n) * a.out.h * a.out.w;
     if (M > 65536 || M * a.in.sw * 4 >= (int64_t(1) << 31) || M * a.out.sw * 4 >= (int64_t(1) << 31) || int64_t(a.out.c) * a.in.c * 4 >= (int64_t(1) << 31))
         return false;
-    return size_t(32) * (a.in.c + 4) * 4 <= size_t(160) * 1024;
+    return size_t(16 * t.pb) * (a.in.c + 4) * 4 <= size_t(160) * 1024;
 }
 
 template <int AT>
 static hipError_t launch_as_t(const ConvArgs& a, hipStream_t stream) {
     constexpr AsTile t = kAsTiles[AT];
     const int64_t M = int64_t(a.out.n) * a.out.h * a.out.w;
-    const dim3 grid(unsigned((M + 31) / 32), unsigned(a.out.c / (16 * t.tnw * t.waves)));
-    const size_t lds = size_t(32) * (a.in.c + 4) * 4;
-    if (a.pre_scale) conv1x1_as_kernel<t.waves, t.tnw, true><<<grid, dim3(64 * t.waves), lds, stream>>>(a);
-    else conv1x1_as_kernel<t.waves, t.tnw, false><<<grid, dim3(64 * t.waves), lds, stream>>>(a);
+    const dim3 grid(unsigned((M + 16 * t.pb - 1) / (16 * t.pb)), unsigned(a.out.c / (16 * t.tnw * t.waves)));
+    const size_t lds = size_t(16 * t.pb) * (a.in.c + 4) * 4;
+    if (a.pre_scale) conv1x1_as_kernel<t.waves, t.tnw, t.pb, true><<<grid, dim3(64 * t.waves), lds, stream>>>(a);
+    else conv1x1_as_kernel<t.waves, t.tnw, t.pb, false><<<grid, dim3(64 * t.waves), lds, stream>>>(a);
     return hipGetLastError();
 }
 
 template <int AT>
 static hipError_t init_as_t() {
     constexpr AsTile t = kAsTiles[AT];
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_as_kernel<t.waves, t.tnw, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_as_kernel<t.waves, t.tnw, t.pb, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_as_kernel<t.waves, t.tnw, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_as_kernel<t.waves, t.tnw, t.pb, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 struct DirectTile { int tn, waves, maxc; };
@@ -638,6 +646,8 @@ hipError_t LaunchConvDirect(const ConvArgs& a_in, int tile, hipStream_t stream) 
         case 4: return launch_as_t<0>(a, stream);
         case 5: return launch_as_t<1>(a, stream);
         case 6: return launch_as_t<2>(a, stream);
+        case 7: return launch_as_t<3>(a, stream);
+        case 8: return launch_as_t<4>(a, stream);
         default: break;
     }
 #define IE_DIR(T) \
@@ -676,6 +686,8 @@ hipError_t InitKernelsDirect() {
     if ((e = init_as_t<0>()) != hipSuccess) return e;
     if ((e = init_as_t<1>()) != hipSuccess) return e;
     if ((e = init_as_t<2>()) != hipSuccess) return e;
+    if ((e = init_as_t<3>()) != hipSuccess) return e;
+    if ((e = init_as_t<4>()) != hipSuccess) return e;
 #define IE_DIRI(T)                                                     \
     if ((e = init_direct_t<false, T>()) != hipSuccess) return e;       \
     if ((e = init_direct_t<true, T>()) != hipSuccess) return e;

@@ -807,9 +807,9 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                 static const int dcfg[6][3] = {{1, 8, 8}, {1, 16, 4}, {1, 9, 8}, {1, 4, 8}, {1, 12, 6}, {2, 8, 4}};   // tn, waves, max chunks
                 static const int wcfg[4][3] = {{1, 8, 9}, {2, 8, 9}, {1, 4, 18}, {2, 4, 18}};                      // window variants: tn, waves, max chunks
                 auto direct_ok = [&](int t) {
-                    if (t < 0 || t >= 13) return false;
-                    if (t >= 10) {     // activations-stationary 1x1 (fp32): the workgroup's 32 pixel rows in LDS, weights streamed from the mirror
-                        static const int acfg[3] = {128, 64, 256};                                                // output channels per workgroup
+                    if (t < 0 || t >= 15) return false;
+                    if (t >= 10) {     // activations-stationary 1x1 (fp32): the workgroup's 32 / 16 pixel rows in LDS, weights streamed from the mirror
+                        static const int acfg[5] = {128, 64, 256, 64, 64};                                        // output channels per workgroup
                         return vec_ok && !in16 && !s.out.f16 && !s.has_in2 && is1x1 && s.in.c % 16 == 0 && N % acfg[t - 10] == 0 && s.out.pitch % 4 == 0 &&
                                s.out.c_off % 4 == 0 && M <= 65536 && 32 * (s.in.c + 4) * 4 <= 160 * 1024;
                     }
@@ -862,7 +862,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                     }
                     else if (f == "direct") {
                         int t = 0;
-                        if (const char* ft = std::getenv("IE_FORCE_TILE")) { int v = std::atoi(ft); if (v >= 0 && v < 13) t = v; }
+                        if (const char* ft = std::getenv("IE_FORCE_TILE")) { int v = std::atoi(ft); if (v >= 0 && v < 15) t = v; }
                         if (direct_ok(t)) { s.algo = ConvAlgo::Direct; s.tile = t; }
                         else if (s.algo == ConvAlgo::Naive && (vec_ok || vec16_ok)) s.algo = ConvAlgo::IgemmVec;
                     }

@@ -666,13 +666,13 @@ def _pointwise_graph(rs, n, h, w, cin, cout, pre, bias, relu):
     return pb.model(g)
 
 
-@pytest.mark.parametrize("tile", [10, 11, 12])
+@pytest.mark.parametrize("tile", [10, 11, 12, 13, 14])
 def test_activations_stationary_1x1_kernel(tmp_path, tile):
-    """conv1x1_as_kernel (direct tiles 10-12, fp32): the workgroup's 32 pixel rows staged once in LDS, weights streamed from the
+    """conv1x1_as_kernel (direct tiles 10-14, fp32): the workgroup's 32 (16) pixel rows staged once in LDS, weights streamed from the
     fragment-major mirror through a register ring - K from 16 (shorter than the ring) to 1008 (not a multiple of the ring depth),
     ragged last row block, prologue / bias / ReLU variants, 128 / 64 / 256 output channels per workgroup; plus the mini DenseNet."""
     rs = np.random.RandomState(500 + tile)
-    per_wg = {10: 128, 11: 64, 12: 256}[tile]
+    per_wg = {10: 128, 11: 64, 12: 256, 13: 64, 14: 64}[tile]
     worst = 0.0
     for case, (n, h, w, cin) in enumerate([(1, 5, 7, 16), (2, 9, 9, 48), (3, 14, 14, 256), (2, 7, 13, 1008), (5, 6, 6, 144), (1, 12, 11, 400)]):
         cout = per_wg * (1 + case % 2)
