@@ -9,9 +9,9 @@ synthetic 3x224x224 images that already sit in the engine's HBM input buffer.  W
 independent shard of `--batch` images (no data-path collective); the only RCCL traffic is the load-time weight
 broadcast from rank 0.  Rank 0 prints ONE JSON line (contract in the task statement) extended with
 
-  roofline      dominant kernel family (conv_igemm_kernel = MFMA implicit-GEMM conv): algorithmic FLOPs per launch /
-                average launch duration, measured with HIP events on the model's stream in an instrumented eager pass
-                of the same forward (EngineProfile), against the 157.3 TFLOP/s dense fp32 MFMA peak
+  roofline      the kernel family with the largest share of the forward's time (kernel name up to '<'): algorithmic FLOPs and
+                bytes per launch / average launch duration, measured with HIP events on the model's stream in an instrumented
+                eager pass of the same forward (EngineProfile), against the dense MFMA peak of the dtype and 8 TB/s HBM
   cpu_baseline  the oracle (numpy restatement of the ONNX ops, oracle/onnx_oracle.py) timed on this host on a bounded
                 sample of the same workload; kind "port" — it is NOT ONNX Runtime (absent from the image)
   p50_ms, modelinfer_*   per-call latency of the device-resident step and of the full ModelInfer C-ABI call

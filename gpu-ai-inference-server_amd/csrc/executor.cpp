@@ -627,7 +627,11 @@ static std::string kernel_label(const Step& s) {
     switch (s.kind) {
         case StepKind::Conv:
             if (s.algo == ConvAlgo::Naive) return "conv_naive_kernel";
-            if (s.algo == ConvAlgo::Direct) return std::string(s.in.f16 ? "conv_direct_kernel<f16,t" : "conv_direct_kernel<f32,t") + std::to_string(s.tile) + ">";
+            if (s.algo == ConvAlgo::Direct) {       // one launcher family, three kernels (kernels_direct.hip): report the one that runs
+                const char* k = s.tile >= 10 ? "conv1x1_as_kernel<f32,t" : s.tile >= kNumDirectBaseTiles ? "conv_win_kernel<f32,t"
+                                             : s.in.f16 ? "conv_direct_kernel<f16,t" : "conv_direct_kernel<f32,t";
+                return std::string(k) + std::to_string(s.tile) + ">";
+            }
             if (s.algo == ConvAlgo::Stem) return s.out.f16 ? "conv_stem_kernel<f16>" : "conv_stem_kernel<f32>";
             if (s.algo == ConvAlgo::Ws1x1) return std::string(s.in.f16 ? "conv1x1_ws_f16_kernel<t" : "conv1x1_ws_f32_kernel<t") + std::to_string(s.tile) + ">";
             if (s.algo == ConvAlgo::Ws3x3) return "conv3x3_ws_f16_kernel<t" + std::to_string(s.tile) + ">";

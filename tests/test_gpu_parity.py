@@ -598,7 +598,7 @@ def test_direct_window_kernel(tmp_path, tile):
     e = rel_err(y, ref)
     print(f"direct window tile {tile}: {nd} convs, kernels {sorted(prof)}, rel err {e:.2e}")
     assert nd >= 6, nd
-    assert f"conv_direct_kernel<f32,t{tile}>" in prof, prof        # ran on the window kernel, not on the implicit-GEMM fallback
+    assert f"conv_win_kernel<f32,t{tile}>" in prof, prof        # ran on the window kernel, not on the implicit-GEMM fallback
     assert e < RTOL, (tile, e)
 
 
@@ -630,7 +630,7 @@ def test_window_kernel_random_same_size_convs(tmp_path):
                 m.Destroy()
             return y, dims, kern
         y, dims, kern = _run_with_env(dict(IE_FORCE_ALGO="direct", IE_FORCE_TILE=str(tile)), go)
-        assert f"conv_direct_kernel<f32,t{tile}>" in kern, (desc, kern)
+        assert f"conv_win_kernel<f32,t{tile}>" in kern, (desc, kern)
         e = rel_err(y, ref)
         worst = max(worst, e)
         assert dims == list(oshape) and e < RTOL, (desc, tile, e)
@@ -690,7 +690,7 @@ def test_activations_stationary_1x1_kernel(tmp_path, tile):
                 m.Destroy()
             return y, dims, kern
         y, dims, kern = _run_with_env(dict(IE_FORCE_ALGO="direct", IE_FORCE_TILE=str(tile)), go)
-        assert f"conv_direct_kernel<f32,t{tile}>" in kern, (case, kern)
+        assert f"conv1x1_as_kernel<f32,t{tile}>" in kern, (case, kern)
         e = rel_err(y, ref)
         worst = max(worst, e)
         assert dims == [n, cout, h, w] and e < RTOL, (tile, case, e)
@@ -709,7 +709,7 @@ def test_activations_stationary_1x1_kernel(tmp_path, tile):
                 m.Destroy()
             return y, kern
         y, kern = _run_with_env(dict(IE_FORCE_ALGO="direct", IE_FORCE_TILE=str(tile)), go_net)
-        assert f"conv_direct_kernel<f32,t{tile}>" in kern, kern       # the bottleneck 1x1s read a slice of the concat buffer
+        assert f"conv1x1_as_kernel<f32,t{tile}>" in kern, kern       # the bottleneck 1x1s read a slice of the concat buffer
         worst = max(worst, rel_err(y, ref))
         assert rel_err(y, ref) < RTOL
     print(f"activations-stationary tile {tile}: worst rel err {worst:.2e}")
