@@ -400,8 +400,10 @@ static hipError_t launch_win_t(const ConvArgs& a, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// "Activations-stationary" 1x1 conv (fp32; direct tiles 10..12) for mid-size pixel counts with long K (DenseNet block 3 at batch
-// 32: M = 6272, N = 128, K = 256..992).  The tiled implicit GEMM has one 64 x 64 workgroup per CU there and pays an LDS round trip
+// "Activations-stationary" 1x1 conv (fp32; direct tiles 10..14).  Written for mid-size pixel counts with long K (DenseNet block 3
+// at batch 32: M = 6272, N = 128, K = 256..992); it also beats the weights-stationary kernel on the big block-1 layers
+// (M = 100352, K = 64..224: coalesced activation rows through LDS instead of 16-byte row-strided fragment loads).
+// The tiled implicit GEMM has one 64 x 64 workgroup per CU on block 3 and pays an LDS round trip
 // + barrier per K tile with nothing to overlap it (16-31 us against an MFMA floor of 4-15 us); the weight slice [128][K] does not fit
 // in LDS, so the weights-stationary kernel does not apply.  Roles swapped: a workgroup copies ITS 32 (16) pixels' K channels into LDS once
 // (coalesced rows, BN+ReLU prologue on the way; one barrier), every wave owns 16*TNW output channels and streams their weights
@@ -555,7 +557,7 @@ static bool as_eligible(const ConvArgs& a, int at) {
     if ((reinterpret_cast<uintptr_t>(a.wfrag) & 15) || (a.bias && (reinterpret_cast<uintptr_t>(a.bias) & 15))) return false;
     if (a.pre_scale && ((reinterpret_cast<uintptr_t>(a.pre_scale) & 15) || (reinterpret_cast<uintptr_t>(a.pre_shift) & 15))) return false;
     const int64_t M = int64_t(a.out.n) * a.out.h * a.out.w;
-    if (M > 65536 || M * a.in.sw * 4 >= (int64_t(1) << 31) || M * a.out.sw * 4 >= (int64_t(1) << 31) || int64_t(a.out.c) * a.in.c * 4 >= (int64_t(1) << 31))
+    if (M > (int64_t(1) << 22) || M * a.in.sw * 4 >= (int64_t(1) << 31) || M * a.out.sw * 4 >= (int64_t(1) << 31) || int64_t(a.out.c) * a.in.c * 4 >= (int64_t(1) << 31))
         return false;
     return size_t(16 * t.pb) * (a.in.c + 4) * 4 <= size_t(160) * 1024;
 }

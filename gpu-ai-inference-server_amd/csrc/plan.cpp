@@ -811,7 +811,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                     if (t >= 10) {     // activations-stationary 1x1 (fp32): the workgroup's 32 / 16 pixel rows in LDS, weights streamed from the mirror
                         static const int acfg[5] = {128, 64, 256, 64, 64};                                        // output channels per workgroup
                         return vec_ok && !in16 && !s.out.f16 && !s.has_in2 && is1x1 && s.in.c % 16 == 0 && N % acfg[t - 10] == 0 && s.out.pitch % 4 == 0 &&
-                               s.out.c_off % 4 == 0 && M <= 65536 && 32 * (s.in.c + 4) * 4 <= 160 * 1024;
+                               s.out.c_off % 4 == 0 && M <= (int64_t(1) << 22) && 32 * (s.in.c + 4) * 4 <= 160 * 1024;
                     }
                     if (t >= 6) {      // fp32, output grid == input grid, activations through an LDS window, fragment-major weights
                         const int* wc = wcfg[t - 6];
@@ -834,13 +834,15 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                     int pick = -1;
                     if (M <= 2048) {                                                       // tiny grids: split K over the waves
                         if (is3x3 && direct_ok(6)) pick = 6;                             // 16-pixel window tiles: 4x the workgroups
+                        else if (is1x1 && direct_ok(13)) pick = 13;                      // 16-pixel activations-stationary tiles
                         for (int t : {1, 0, 4, 3}) if (pick < 0 && direct_ok(t)) pick = t;
                         if (pick >= 0) { s.algo = ConvAlgo::Direct; s.tile = pick; }
                     } else if (in16) {
                         if (is1x1) { for (int t : {0, 2, 4}) if (pick < 0 && ws16_ok(t)) pick = t; if (pick >= 0) { s.algo = ConvAlgo::Ws1x1; s.tile = pick; } }
                         else if (is3x3) { for (int t : {2, 1, 0}) if (pick < 0 && ws3_ok(t)) pick = t; if (pick >= 0) { s.algo = ConvAlgo::Ws3x3; s.tile = pick; } }
                     } else {
-                        if (is1x1 && M >= 20000) { for (int t : {0, 2, 4}) if (pick < 0 && ws32_ok(t)) pick = t; if (pick >= 0) { s.algo = ConvAlgo::Ws1x1; s.tile = pick; } }
+                        if (is1x1 && direct_ok(10)) { s.algo = ConvAlgo::Direct; s.tile = 10; }      // activations-stationary 1x1: 128-channel multiples whose 32 pixel rows fit in LDS
+                        else if (is1x1 && M >= 20000) { for (int t : {0, 2, 4}) if (pick < 0 && ws32_ok(t)) pick = t; if (pick >= 0) { s.algo = ConvAlgo::Ws1x1; s.tile = pick; } }
                         else if (raster_ok && M >= 20000 && N <= 64) { s.algo = ConvAlgo::Raster3x3; s.tile = N <= 32 ? 0 : 4; }
                         else if (is3x3 && M <= 8192) { if (direct_ok(4)) { s.algo = ConvAlgo::Direct; s.tile = 4; } }
                     }
