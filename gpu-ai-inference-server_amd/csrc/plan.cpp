@@ -50,6 +50,9 @@ struct Lowering {
     std::vector<Val> vals;
     std::map<std::string, int> val_of;
     std::vector<LNode> nodes;
+    // initializers produced at plan time by folding shape-only ops (Unsqueeze / Squeeze / Reshape / Flatten / Identity) whose
+    // input is itself a constant: model-zoo exports of Caffe BN+Scale pairs route the [C] scale and bias through Unsqueeze nodes
+    std::map<std::string, OnnxTensor> derived;
 
     explicit Lowering(const OnnxModel& mm) : m(mm) {}
 
@@ -75,7 +78,9 @@ struct Lowering {
     }
     const OnnxTensor* init(const std::string& name) const {
         auto it = m.initializers.find(name);
-        return it == m.initializers.end() ? nullptr : &it->second;
+        if (it != m.initializers.end()) return &it->second;
+        auto jt = derived.find(name);
+        return jt == derived.end() ? nullptr : &jt->second;
     }
     std::vector<int> consumers(int v) const {
         std::vector<int> out;
@@ -86,13 +91,20 @@ struct Lowering {
     }
 
     // A constant that broadcasts along the channel axis of `x` (numpy rules): scalar, [C], [1,C], [C,1,1], [1,C,1,1].
-    bool per_channel_const(const OnnxTensor& t, const Val& x, std::vector<float>& out) const {
+    // legacy_axis >= 0: opset < 7 broadcasting (attributes broadcast=1, axis=k): the constant's dims align with the activation's
+    // dims starting at axis k instead of at the trailing end.
+    bool per_channel_const(const OnnxTensor& t, const Val& x, std::vector<float>& out, int64_t legacy_axis = -1) const {
         if (t.dtype != ONNX_FLOAT && t.dtype != ONNX_DOUBLE && t.dtype != ONNX_FLOAT16) return false;
         int64_t n = t.numel();
         if (n == 1) { out.assign(size_t(x.c), t.f[0]); return true; }
         if (n != x.c) return false;
         size_t rank = x.dims.size();
         std::vector<int64_t> d = t.dims;
+        if (legacy_axis >= 0) {
+            if (size_t(legacy_axis) + d.size() > rank) return false;
+            d.insert(d.begin(), size_t(legacy_axis), 1);
+            while (d.size() < rank) d.push_back(1);
+        }
         while (d.size() < rank) d.insert(d.begin(), 1);
         if (d.size() != rank) return false;
         for (size_t k = 0; k < rank; ++k) if (d[k] != (k == 1 ? x.c : 1)) {
@@ -227,6 +239,69 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
         auto act_input = [&](size_t k) { return k < on.inputs.size() && !on.inputs[k].empty() && !L.init(on.inputs[k]); };
         std::vector<int64_t> odims;
 
+        // ---- shape-only ops on constants fold into a derived initializer (nothing is emitted) ----
+        if ((op == "Unsqueeze" || op == "Squeeze" || op == "Reshape" || op == "Flatten" || op == "Identity") && L.init(on.inputs[0])) {
+            OnnxTensor t = *L.init(on.inputs[0]);
+            auto axes_of = [&]() {
+                std::vector<int64_t> ax = on.attr_ints("axes", {});
+                if (ax.empty() && on.inputs.size() > 1 && !on.inputs[1].empty()) {       // opset >= 13: axes is an input
+                    const OnnxTensor* at = L.init(on.inputs[1]);
+                    if (!at) fail(op + " " + n.name + ": axes must be an initializer");
+                    ax = at->i;
+                }
+                return ax;
+            };
+            if (op == "Unsqueeze") {
+                std::vector<int64_t> ax = axes_of();
+                if (ax.empty()) fail("Unsqueeze " + n.name + ": axes are required");
+                const int64_t orank = int64_t(t.dims.size() + ax.size());
+                for (auto& a : ax) { if (a < 0) a += orank; if (a < 0 || a >= orank) fail("Unsqueeze " + n.name + ": axis out of range"); }
+                std::sort(ax.begin(), ax.end());
+                std::vector<int64_t> nd;
+                size_t src = 0;
+                for (int64_t k = 0; k < orank; ++k) {
+                    if (std::binary_search(ax.begin(), ax.end(), k)) nd.push_back(1);
+                    else nd.push_back(t.dims.at(src++));
+                }
+                t.dims = nd;
+            } else if (op == "Squeeze") {
+                std::vector<int64_t> ax = axes_of();
+                const int64_t rank = int64_t(t.dims.size());
+                for (auto& a : ax) if (a < 0) a += rank;
+                std::vector<int64_t> nd;
+                for (int64_t k = 0; k < rank; ++k) {
+                    const bool listed = std::find(ax.begin(), ax.end(), k) != ax.end();
+                    if (listed && t.dims[size_t(k)] != 1) fail("Squeeze " + n.name + ": cannot squeeze a dimension of size != 1");
+                    if (ax.empty() ? t.dims[size_t(k)] != 1 : !listed) nd.push_back(t.dims[size_t(k)]);
+                }
+                t.dims = nd;
+            } else if (op == "Reshape") {
+                const OnnxTensor* shp = on.inputs.size() > 1 ? L.init(on.inputs[1]) : nullptr;
+                std::vector<int64_t> d = shp ? shp->i : on.attr_ints("shape", {});
+                if (d.empty() && t.numel() != 1) fail("Reshape " + n.name + ": shape must be an initializer");
+                int64_t known = 1, neg = -1;
+                for (size_t k = 0; k < d.size(); ++k) {
+                    if (d[k] == 0 && k < t.dims.size()) d[k] = t.dims[k];
+                    if (d[k] == -1) neg = int64_t(k); else known *= d[k];
+                }
+                if (neg >= 0 && known > 0) d[size_t(neg)] = t.numel() / known;
+                int64_t tot = 1; for (auto v : d) tot *= v;
+                if (tot != t.numel()) fail("Reshape " + n.name + ": element count mismatch");
+                t.dims = d;
+            } else if (op == "Flatten") {
+                int64_t ax = on.attr_i("axis", 1);
+                if (ax < 0) ax += int64_t(t.dims.size());
+                int64_t a = 1, b = 1;
+                for (size_t k = 0; k < t.dims.size(); ++k) (int64_t(k) < ax ? a : b) *= t.dims[k];
+                t.dims = {a, b};
+            }
+            t.name = on.outputs[0];
+            if (L.derived.count(t.name) || m.initializers.count(t.name) || L.val_of.count(t.name))
+                fail("ONNX graph error: value defined twice: " + t.name);
+            L.derived[t.name] = std::move(t);
+            continue;
+        }
+
         if (op == "Conv") {
             if (!act_input(0)) fail("Conv " + n.name + ": constant input is not supported");
             const OnnxTensor* w = L.init(on.inputs.at(1));
@@ -322,7 +397,16 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                 std::vector<float> pc;
                 // rank-1 constant against a rank-2 activation aligns with the last (= channel) axis
                 const Val& X = L.vals[x];
-                bool ok = L.per_channel_const(*c, X, pc);
+                // opset < 7 (Caffe2-era exports): Add/Mul carry broadcast=1 and an axis that places the constant's dims inside the
+                // activation's (axis=1 with a [C] constant = per channel); without an axis the constant aligns with the trailing dims
+                int64_t legacy_axis = -1;
+                if (m.opset > 0 && m.opset < 7 && on.attr_i("broadcast", 0) != 0 && on.attrs.count("axis")) {
+                    legacy_axis = on.attr_i("axis", 0);
+                    if (legacy_axis < 0) legacy_axis += int64_t(X.dims.size());
+                }
+                if (m.opset > 0 && m.opset < 7 && on.attr_i("broadcast", 0) == 0 && c->dims != X.dims && c->numel() != 1)
+                    fail(op + " " + n.name + ": operand shapes differ and the opset-" + std::to_string(m.opset) + " broadcast attribute is not set");
+                bool ok = L.per_channel_const(*c, X, pc, legacy_axis);
                 if (!ok && X.dims.size() == 2 && c->dims.size() == 1 && c->numel() == X.c) { pc = c->f; ok = true; }
                 if (!ok && X.dims.size() == 2 && c->dims.size() == 2 && c->dims[0] == 1 && c->dims[1] == X.c) { pc = c->f; ok = true; }
                 if (!ok) fail(op + " " + n.name + ": constant operand must broadcast per channel");
@@ -371,6 +455,21 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
             n.kind = L_GAP;
             n.in = {x};
             odims = {X.n, X.c, 1, 1};
+        } else if (op == "Unsqueeze") {
+            // [N,C] -> [N,C,1,1]: storage is unchanged when only trailing unit axes are added
+            int x = in_val(0);
+            const Val& X = L.vals[x];
+            std::vector<int64_t> ax = on.attr_ints("axes", {});
+            if (ax.empty() && on.inputs.size() > 1) { const OnnxTensor* at = L.init(on.inputs[1]); if (at) ax = at->i; }
+            const int64_t orank = int64_t(X.dims.size() + ax.size());
+            for (auto& a : ax) if (a < 0) a += orank;
+            std::sort(ax.begin(), ax.end());
+            if (ax.empty() || X.h * X.w != 1 || X.dims.size() < 2 || ax[0] < int64_t(X.dims.size()) || orank > 4)
+                fail("Unsqueeze " + n.name + ": only trailing unit axes on [N,C] tensors are supported");
+            n.kind = L_ALIAS;
+            n.in = {x};
+            odims = X.dims;
+            while (int64_t(odims.size()) < orank) odims.push_back(1);
         } else if (op == "Flatten" || op == "Reshape" || op == "Identity" || op == "Dropout" || op == "Squeeze") {
             int x = in_val(0);
             const Val& X = L.vals[x];
@@ -443,6 +542,10 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
             int ci = L.consumers(cv.out)[0];
             LNode& b = L.nodes[ci];
             if (b.kind == L_AFFINE) {
+                // Once a residual has been absorbed the epilogue computes conv + bias + res: scaling weights and bias would leave
+                // the shortcut unscaled (pre-activation / ResNet-v2 blocks: Conv -> Add -> BN -> ReLU).  The BN then becomes the
+                // consumer's prologue (fusion 3) or a standalone eltwise step (fusion 4).
+                if (cv.res >= 0) break;
                 if (cv.bias.empty()) cv.bias.assign(size_t(cout), 0.f);
                 for (int64_t o = 0; o < cout; ++o) {
                     for (size_t k = 0; k < kper; ++k) cv.w[size_t(o) * kper + k] *= b.s[o];

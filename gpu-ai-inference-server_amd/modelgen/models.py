@@ -54,9 +54,9 @@ class GraphBuilder:
             pb.attr_ints("strides", [stride, stride])]))
         return y
 
-    def bn(self, x: str, c: int, name: str | None = None, eps: float = 1e-5) -> str:
+    def bn(self, x: str, c: int, name: str | None = None, eps: float = 1e-5, g_center: float = 1.0) -> str:
         name = name or self._uid("bn")
-        g = np.float32(1.0) + (rng.uniform(self.seed, name + "_g", c) - np.float32(0.5)) * np.float32(0.2)
+        g = np.float32(g_center) + (rng.uniform(self.seed, name + "_g", c) - np.float32(0.5)) * np.float32(0.2)
         b = (rng.uniform(self.seed, name + "_b", c) - np.float32(0.5)) * np.float32(0.2)
         m = (rng.uniform(self.seed, name + "_m", c) - np.float32(0.5)) * np.float32(0.2)
         v = np.float32(0.5) + rng.uniform(self.seed, name + "_v", c)
@@ -104,11 +104,14 @@ class GraphBuilder:
 
 def densenet(batch: int | str = 1, *, growth: int = 32, blocks: Sequence[int] = (6, 12, 24, 16),
              stem: int = 64, bn_size: int = 4, image: int = 224, classes: int = 1000, seed: int = 121,
-             in_name: str = "data_0", out_name: str = "fc6_1", caffe_scale: bool = False) -> bytes:
+             in_name: str = "data_0", out_name: str = "fc6_1", caffe_scale: bool | str = False) -> bytes:
     """DenseNet-BC-style graph (DenseNet-121 with the defaults).
 
-    caffe_scale=True follows each BatchNormalization with broadcast Mul+Add by [C,1,1] constants, the
-    way Caffe BN+Scale pairs are sometimes exported (SURVEY.md §2.3 last row).
+    caffe_scale follows each BatchNormalization with the Mul+Add of a Caffe Scale layer (SURVEY.md §2.3 last row), in the three
+    forms exporters of the model-zoo Caffe2 DenseNet-121 produce:
+      True            [C,1,1] initializers, numpy broadcasting
+      "unsqueeze"     [C] initializers routed through Unsqueeze(axes=[1,2]) nodes (opset >= 7 exports)
+      "legacy_axis"   [C] initializers with the opset-6 attributes broadcast=1, axis=1 (the whole model is then opset 6)
     """
     gb = GraphBuilder("densenet", seed)
 
@@ -118,8 +121,18 @@ def densenet(batch: int | str = 1, *, growth: int = 32, blocks: Sequence[int] = 
             nm = gb._uid("scale")
             s = np.float32(1.0) + (rng.uniform(seed, nm + "_s", c) - np.float32(0.5)) * np.float32(0.1)
             t = (rng.uniform(seed, nm + "_t", c) - np.float32(0.5)) * np.float32(0.1)
-            y = gb.simple("Mul", [y, gb.init(nm + "_s", s.reshape(c, 1, 1))])
-            y = gb.simple("Add", [y, gb.init(nm + "_t", t.reshape(c, 1, 1))])
+            if caffe_scale == "unsqueeze":
+                su = gb.simple("Unsqueeze", [gb.init(nm + "_s", s)], [pb.attr_ints("axes", [1, 2])])
+                tu = gb.simple("Unsqueeze", [gb.init(nm + "_t", t)], [pb.attr_ints("axes", [1, 2])])
+                y = gb.simple("Mul", [y, su])
+                y = gb.simple("Add", [y, tu])
+            elif caffe_scale == "legacy_axis":
+                legacy = [pb.attr_int("axis", 1), pb.attr_int("broadcast", 1)]
+                y = gb.simple("Mul", [y, gb.init(nm + "_s", s)], legacy)
+                y = gb.simple("Add", [y, gb.init(nm + "_t", t)], legacy)
+            else:
+                y = gb.simple("Mul", [y, gb.init(nm + "_s", s.reshape(c, 1, 1))])
+                y = gb.simple("Add", [y, gb.init(nm + "_t", t.reshape(c, 1, 1))])
         return y
 
     x = gb.conv(in_name, 3, stem, 7, stride=2, pad=3, name="conv1")
@@ -150,7 +163,8 @@ def densenet(batch: int | str = 1, *, growth: int = 32, blocks: Sequence[int] = 
                             [out_name], fc, [pb.attr_ints("kernel_shape", [1, 1]), pb.attr_ints("pads", [0] * 4),
                                              pb.attr_ints("strides", [1, 1]), pb.attr_int("group", 1),
                                              pb.attr_ints("dilations", [1, 1])]))
-    return gb.finish([(in_name, [batch, 3, image, image])], [(out_name, [batch, classes, 1, 1])], opset=11)
+    return gb.finish([(in_name, [batch, 3, image, image])], [(out_name, [batch, classes, 1, 1])],
+                     opset=6 if caffe_scale == "legacy_axis" else 11)
 
 
 def densenet121(batch: int | str = 1) -> bytes:
@@ -206,6 +220,40 @@ def resnet_block(batch: int | str = 2, c: int = 32, image: int = 16, seed: int =
     gb.nodes.append(pb.node("MaxPool", [s], ["y"], "final_pool", [
         pb.attr_ints("kernel_shape", [2, 2]), pb.attr_ints("pads", [0] * 4), pb.attr_ints("strides", [2, 2])]))
     return gb.finish([("x", [batch, 3, image, image])], [("y", [batch, c, image // 4, image // 4])], opset=11)
+
+
+def preact_block(batch: int | str = 2, c: int = 32, image: int = 16, seed: int = 53, final_relu: bool = True) -> bytes:
+    """Pre-activation (ResNet-v2) residual blocks: the Add of a block is followed by the NEXT block's BN, so the graph holds
+    Conv -> Add -> BN(gamma != 1) -> ReLU chains, and ends in Add -> BN -> [ReLU] -> GlobalAveragePool.
+
+    Regression graph for the planner: a BN that follows an absorbed residual Add must scale the shortcut too
+    (relu(s*(conv+res)+t), not relu(s*conv+res+t)), so it cannot be folded into the conv's weights.
+    """
+    gb = GraphBuilder("preact_block", seed)
+    x = gb.conv("x", 3, c, 3, pad=1, bias=True)
+    for _ in range(2):
+        y = gb.conv(gb.relu(gb.bn(x, c, g_center=1.6)), c, c, 3, pad=1)
+        y = gb.conv(gb.relu(gb.bn(y, c, g_center=0.7)), c, c, 3, pad=1, bias=True)
+        x = gb.simple("Add", [y, x])
+    z = gb.bn(x, c, g_center=2.5)
+    if final_relu:
+        z = gb.relu(z)
+    gb.nodes.append(pb.node("GlobalAveragePool", [z], ["y"], "final_gap"))
+    return gb.finish([("x", [batch, 3, image, image])], [("y", [batch, c, 1, 1])], opset=11)
+
+
+def two_input_graph(batch: int | str = 2, ca: int = 8, cb: int = 16, image: int = 12, seed: int = 54) -> bytes:
+    """Two graph inputs declared in the order (b_in, a_in) with different channel counts, merged by Concat after one conv each.
+
+    ModelInfer must place payloads by graph input NAME -> graph index (model.cpp:1174-1190), whatever order the caller lists them in.
+    """
+    gb = GraphBuilder("two_input", seed)
+    ya = gb.relu(gb.conv("a_in", ca, 16, 3, pad=1, bias=True))
+    yb = gb.relu(gb.conv("b_in", cb, 16, 1, bias=True))
+    x = gb.concat([ya, yb])
+    x = gb.conv(x, 32, 24, 3, pad=1)
+    gb.nodes.append(pb.node("GlobalAveragePool", [x], ["y"], "final_gap"))
+    return gb.finish([("b_in", [batch, cb, image, image]), ("a_in", [batch, ca, image, image])], [("y", [batch, 24, 1, 1])], opset=11)
 
 
 def resnet(batch: int | str = 1, *, layers: Sequence[int] = (3, 4, 6, 3), width: int = 64, image: int = 224, classes: int = 1000,

@@ -32,6 +32,14 @@ MINI = {
                             "data_0", (3, 3, 64, 64)),
     "mini_gemm_mlp": (lambda m: m.gemm_mlp(4), "x", (4, 64, 1, 1)),
     "mini_resnet_block": (lambda m: m.resnet_block(2), "x", (2, 3, 16, 16)),
+    # pre-activation residual blocks: Conv -> Add -> BN(gamma != 1) -> [ReLU] -> GAP (the BN must scale the shortcut too)
+    "mini_preact": (lambda m: m.preact_block(2), "x", (2, 3, 16, 16)),
+    "mini_preact_norelu": (lambda m: m.preact_block(2, final_relu=False), "x", (2, 3, 16, 16)),
+    # the two other export forms of a Caffe Scale layer: [C] constants through Unsqueeze nodes, and opset-6 broadcast=1/axis=1
+    "mini_densenet_unsqueeze": (lambda m: m.densenet(3, growth=12, blocks=(2, 2, 2), stem=24, image=64, classes=17, seed=6,
+                                                     caffe_scale="unsqueeze"), "data_0", (3, 3, 64, 64)),
+    "mini_densenet_legacy": (lambda m: m.densenet(3, growth=12, blocks=(2, 2, 2), stem=24, image=64, classes=17, seed=6,
+                                                  caffe_scale="legacy_axis"), "data_0", (3, 3, 64, 64)),
 }
 
 
@@ -49,6 +57,7 @@ def model_repo(tmp_path_factory):
             dst.write(src.read())
     for name, (mk, _, _) in MINI.items():
         models.write_repo(root, name, mk(models))
+    models.write_repo(root, "mini_two_input", models.two_input_graph("N"))
     return root
 
 

@@ -76,10 +76,15 @@ def run_torch(model: O.Model, feeds: dict, keep=()):
                 y = y + a.get("beta", 1.0) * i[2]
         elif n.op == "MatMul":
             y = i[0] @ i[1]
-        elif n.op == "Add":
-            y = i[0] + i[1]
-        elif n.op == "Mul":
-            y = i[0] * i[1]
+        elif n.op in ("Add", "Mul"):
+            b = i[1]
+            if 0 < model.opset < 7 and a.get("broadcast", 0) and "axis" in a:      # opset-6 form: B aligned at `axis` of A
+                b = b.reshape((1,) * a["axis"] + tuple(b.shape) + (1,) * (i[0].ndim - a["axis"] - b.ndim))
+            y = i[0] + b if n.op == "Add" else i[0] * b
+        elif n.op == "Unsqueeze":
+            y = i[0]
+            for ax in sorted(a["axes"]):
+                y = y.unsqueeze(ax)
         elif n.op == "Flatten":
             y = torch.flatten(i[0], a.get("axis", 1))
         else:
@@ -90,6 +95,17 @@ def run_torch(model: O.Model, feeds: dict, keep=()):
     return {o[0]: env[o[0]].numpy() for o in model.outputs}, kept
 
 
+def _save(name, **arrays):
+    """Existing fixtures are left alone (np.savez output is not byte-stable) unless --force is given."""
+    path = os.path.join(HERE, name + ".npz")
+    if os.path.exists(path) and "--force" not in sys.argv:
+        old = np.load(path)
+        for k, v in arrays.items():
+            assert np.array_equal(old[k], v), f"{name}.{k}: regenerated values differ from the committed fixture"
+        return
+    np.savez(path, **arrays)
+
+
 def main():
     torch.set_num_threads(8)
     # ---- test_model ------------------------------------------------------------------
@@ -97,7 +113,7 @@ def main():
     probes = np.array([[-0.01349723, -1.0577109, 0.82254493], [1, 1, 1], [1, 2, 3], [0, 0, 0], [-1, 2, -3],
                        [0.5, -0.25, 2.0]], np.float32)
     outs = np.stack([run_torch(m, {"input": p[None]})[0]["output"][0] for p in probes])
-    np.savez(os.path.join(HERE, "test_model.npz"), inputs=probes, outputs_f64=outs,
+    _save("test_model", inputs=probes, outputs_f64=outs,
              ort_recorded_input=np.array([[-0.01349723, -1.0577109, 0.82254493]], np.float32),
              ort_recorded_output=np.array([[-0.6017066, 1.8522782]], np.float32))
     print("test_model", outs)
@@ -110,14 +126,28 @@ def main():
                                                 seed=6, caffe_scale=True), "data_0", (3, 3, 64, 64)),
         "mini_gemm_mlp": (models.gemm_mlp(4), "x", (4, 64, 1, 1)),
         "mini_resnet_block": (models.resnet_block(2), "x", (2, 3, 16, 16)),
+        "mini_preact": (models.preact_block(2), "x", (2, 3, 16, 16)),
+        "mini_preact_norelu": (models.preact_block(2, final_relu=False), "x", (2, 3, 16, 16)),
+        "mini_densenet_unsqueeze": (models.densenet(3, growth=12, blocks=(2, 2, 2), stem=24, image=64, classes=17,
+                                                    seed=6, caffe_scale="unsqueeze"), "data_0", (3, 3, 64, 64)),
+        "mini_densenet_legacy": (models.densenet(3, growth=12, blocks=(2, 2, 2), stem=24, image=64, classes=17,
+                                                 seed=6, caffe_scale="legacy_axis"), "data_0", (3, 3, 64, 64)),
     }
     for name, (mb, iname, ishape) in minis.items():
         mm = O.load_model(mb)
         x = models.synthetic_input(ishape, stream=name)
         out, _ = run_torch(mm, {iname: x})
         (oname, y), = out.items()
-        np.savez(os.path.join(HERE, name + ".npz"), output_f64=y)
+        _save(name, output_f64=y)
         print(name, y.shape, float(np.abs(y).max()))
+
+    # ---- two graph inputs (ordering rule of model.cpp:1174-1190) ---------------------------
+    mm = O.load_model(models.two_input_graph(2))
+    xa = models.synthetic_input((2, 8, 12, 12), stream="two_input/a")
+    xb = models.synthetic_input((2, 16, 12, 12), stream="two_input/b")
+    out, _ = run_torch(mm, {"a_in": xa, "b_in": xb})
+    _save("mini_two_input", output_f64=out["y"])
+    print("mini_two_input", out["y"].shape, float(np.abs(out["y"]).max()))
 
     # ---- DenseNet-121, batch 2 -------------------------------------------------------
     mb = models.densenet121(2)
@@ -127,7 +157,7 @@ def main():
     ends = [concat_outs[5], concat_outs[17], concat_outs[41], concat_outs[57]]
     out, kept = run_torch(md, {"data_0": x}, keep=ends)
     stats = np.array([[float(kept[k].mean()), float(kept[k].std())] for k in ends])
-    np.savez(os.path.join(HERE, "densenet121_b2.npz"), logits_f64=out["fc6_1"].reshape(2, 1000), block_end_stats=stats)
+    _save("densenet121_b2", logits_f64=out["fc6_1"].reshape(2, 1000), block_end_stats=stats)
     print("densenet121", out["fc6_1"].reshape(2, 1000)[:, :4], stats)
 
 

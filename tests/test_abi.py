@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import ROOT
+from conftest import MINI, ROOT
 from gpu_ai_inference_server_amd import binding as B
 from gpu_ai_inference_server_amd import build
 
@@ -102,7 +102,7 @@ def test_repository_and_manager_semantics(model_repo, tmp_path):
     assert newroot.is_dir() and m2.ListModels() == []
     m2.Shutdown()
     m3 = B.NewInferenceManager(model_repo)
-    assert m3.ListModels() == sorted(["test_model", "mini_densenet", "mini_densenet_scale", "mini_gemm_mlp", "mini_resnet_block"])
+    assert m3.ListModels() == sorted(["test_model", "mini_two_input"] + list(MINI))
     m3.Shutdown()
 
 

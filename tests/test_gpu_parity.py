@@ -720,9 +720,9 @@ def test_activations_stationary_1x1_kernel(tmp_path, tile):
 # model's own fp32), so there is no reference-side number to pin: "parity unpinned".  The checker is the float64 oracle /
 # fixture; the tolerance is this repo's own statement: activations and weights are rounded to half (2^-11 relative per
 # element), every accumulation, BN scale/shift, bias and split-K slab is fp32, so the error is a rounding random walk over
-# the layers.  Bound used: 1e-2 of max|ref| per graph (2e-2 for the 121-layer DenseNet) plus identical top-1 classes.
+# the layers.  Bound used: 3e-3 of max|ref| per graph (observed 3e-4 ... 1e-3; DenseNet-121 6.5e-4) plus identical top-1 classes.
 # ---------------------------------------------------------------------------------------------------------------------
-F16_RTOL = 1e-2
+F16_RTOL = 3e-3
 
 
 def _f16_env(**extra):
@@ -885,7 +885,7 @@ def test_fp16_densenet121_fixture_and_batch_independence(densenet_repo, tmp_path
         assert dims == [2, 1000, 1, 1]
         e = rel_err(y.reshape(2, 1000), g["logits_f64"])
         print(f"densenet121 fp16 B=2: rel err vs float64 fixture {e:.2e}")
-        assert e < 2e-2
+        assert e < F16_RTOL
         assert np.argmax(y.reshape(2, 1000), 1).tolist() == np.argmax(g["logits_f64"], 1).tolist()
         x32 = models.synthetic_input((32, 3, 224, 224), stream="b32")
         y32, _ = infer(mgr, "densenet_onnx", "data_0", x32, "fc6_1", [32, 1000, 1, 1])
@@ -893,7 +893,7 @@ def test_fp16_densenet121_fixture_and_batch_independence(densenet_repo, tmp_path
         assert np.isfinite(y32).all() and np.abs(y32).max() < 50
         for i in (0, 17, 31):
             y1, _ = infer(mgr, "densenet_onnx", "data_0", x32[i:i + 1], "fc6_1", [1, 1000, 1, 1])
-            assert rel_err(y1.reshape(1000), y32[i]) < 5e-3
+            assert rel_err(y1.reshape(1000), y32[i]) < F16_RTOL
     finally:
         mgr.Shutdown()
 
@@ -988,7 +988,7 @@ def test_resnet50_b2_vs_float64_oracle(tmp_path, prec):
     assert dims == [2, 1000]
     e = rel_err(y, ref)
     print(f"resnet50 {prec} B=2: rel err vs float64 oracle {e:.2e}")
-    assert e < (RTOL if prec == "fp32" else 2e-2)
+    assert e < (RTOL if prec == "fp32" else F16_RTOL)
     assert np.argmax(y, 1).tolist() == np.argmax(ref, 1).tolist()
 
 
@@ -1106,3 +1106,126 @@ def test_plan_cache_is_bounded(model_repo):
     import tempfile
     with tempfile.TemporaryDirectory() as tmp:
         _run_with_env(dict(IE_MAX_PLANS="2", IE_AUTOTUNE="0"), lambda: go(tmp))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs at their own sizes, and the multi-input ordering rule
+# ---------------------------------------------------------------------------------------------------------------------
+def _with_precision_config(densenet_repo, tmp_path, extra):
+    import shutil
+    root = str(tmp_path / "repo")
+    shutil.copytree(densenet_repo, root)
+    cfg_path = os.path.join(root, "densenet_onnx", "1", "config.json")
+    with open(cfg_path) as f:
+        cfg = f.read()
+    with open(cfg_path, "w") as f:
+        f.write(cfg[:-1] + extra + "}")
+    return root
+
+
+def test_config2_fp16_densenet121_b128(densenet_repo, tmp_path):
+    """BASELINE configs[2] at its own size: DenseNet-121, fp16 mode, batch 128 through ModelInfer (77 MB FLOAT32 payload).
+    Other output grids, other kernel choices and multi-round persistent loops than the B=2 / B=32 cases.  Size-independent
+    property: each image's logits equal that image run alone (up to fp16 summation-order rounding); plus the float64 oracle
+    on 2 of the 128 images, and a batch permutation."""
+    root = _with_precision_config(densenet_repo, tmp_path, ',"precision":"fp16"')
+    mgr = B.NewInferenceManager(root)
+    try:
+        mgr.LoadModel("densenet_onnx")
+        x = models.synthetic_input((128, 3, 224, 224), stream="b128")
+        y, dims = infer(mgr, "densenet_onnx", "data_0", x, "fc6_1", [128, 1000, 1, 1])
+        assert dims == [128, 1000, 1, 1]
+        y = y.reshape(128, 1000)
+        assert np.isfinite(y).all() and np.abs(y).max() < 50
+        for i in (0, 61, 100, 127):
+            y1, _ = infer(mgr, "densenet_onnx", "data_0", x[i:i + 1], "fc6_1", [1, 1000, 1, 1])
+            e = rel_err(y1.reshape(1000), y[i])
+            assert e < F16_RTOL, (i, e)
+        perm = np.random.RandomState(1).permutation(128)
+        yp, _ = infer(mgr, "densenet_onnx", "data_0", x[perm], "fc6_1", [128, 1000, 1, 1])
+        assert rel_err(yp.reshape(128, 1000), y[perm]) < F16_RTOL
+        om = O.load_model(models.densenet121(2))
+        yo = O.run(om, {"data_0": x[[5, 90]]}, dtype=np.float64)["fc6_1"].reshape(2, 1000)
+        e = rel_err(y[[5, 90]], yo)
+        print(f"densenet121 fp16 B=128: rel err vs float64 oracle on images 5, 90: {e:.2e}")
+        assert e < F16_RTOL
+        assert np.argmax(y[[5, 90]], 1).tolist() == np.argmax(yo, 1).tolist()
+    finally:
+        mgr.Shutdown()
+
+
+def test_config3_fp16_b1024_over_8_shards(densenet_repo, tmp_path):
+    """BASELINE configs[3] on the one GPU of this box: fp16 DenseNet-121, one ModelInfer request of 1024 images (616 MB) cut
+    into 8 contiguous slices of 128 over 8 replicas (IE_SHARD_DEVICES=0,...: all on device 0 here; on an 8-GPU node the same
+    code path puts one replica per device).  Every slice must equal the unsharded engine's answer for those 128 images --
+    bit for bit, since replicas run the same plan (the kernel search is pinned off so every replica picks the same kernels)."""
+    root = _with_precision_config(densenet_repo, tmp_path, ',"precision":"fp16"')
+    path = os.path.join(root, "densenet_onnx", "1")
+    base = models.synthetic_input((128, 3, 224, 224), stream="b1024")
+    rs = np.random.RandomState(3)
+    perms = [np.arange(128)] + [rs.permutation(128) for _ in range(7)]
+    x = np.concatenate([base[p_] for p_ in perms], 0)
+    assert x.shape == (1024, 3, 224, 224)
+    outs128 = [B.OutputConfig("fc6_1", Shape=[128, 1000, 1, 1], DataType="FLOAT32")]
+    outs1024 = [B.OutputConfig("fc6_1", Shape=[1024, 1000, 1, 1], DataType="FLOAT32")]
+
+    def unsharded():
+        m = B.CreateModel(path, "densenet_onnx")
+        try:
+            assert B.ShardStats(m) == (1, 0)
+            return m.Infer([B.TensorData("data_0", B.DataTypeFloat32, B.Shape([128, 3, 224, 224]), base)], outs128)[0].Data.reshape(128, 1000).copy()
+        finally:
+            m.Destroy()
+
+    def sharded():
+        m = B.CreateModel(path, "densenet_onnx")
+        try:
+            assert B.ShardStats(m) == (8, 0)
+            r = m.Infer([B.TensorData("data_0", B.DataTypeFloat32, B.Shape([1024, 3, 224, 224]), x)], outs1024)[0]
+            assert r.Shape.Dims == [1024, 1000, 1, 1]
+            assert B.ShardStats(m) == (8, 1)
+            return r.Data.reshape(1024, 1000).copy()
+        finally:
+            m.Destroy()
+    y128 = _run_with_env(dict(IE_AUTOTUNE="0"), unsharded)
+    y = _run_with_env(dict(IE_AUTOTUNE="0", IE_SHARD_DEVICES="0,0,0,0,0,0,0,0"), sharded)
+    assert np.isfinite(y).all()
+    for k, p_ in enumerate(perms):
+        got = y[128 * k:128 * (k + 1)]
+        if k == 0:
+            np.testing.assert_array_equal(got, y128)        # same rows, same plan: identical bits
+        else:
+            assert rel_err(got, y128[p_]) < F16_RTOL, k   # a permuted slice: other images share a tile, fp16 rounding only
+            assert (np.argmax(got, 1) == np.argmax(y128[p_], 1)).mean() > 0.98
+
+
+def test_two_input_graph_orders_inputs_by_graph_index(mgr):
+    """InferONNX (model.cpp:1174-1190) places each payload at the graph index of its NAME, whatever order the caller lists
+    the tensors in; graph order here is (b_in, a_in)."""
+    g = np.load(os.path.join(GOLD, "mini_two_input.npz"))["output_f64"]
+    xa = models.synthetic_input((2, 8, 12, 12), stream="two_input/a")
+    xb = models.synthetic_input((2, 16, 12, 12), stream="two_input/b")
+    ta = B.TensorData("a_in", B.DataTypeFloat32, B.Shape([2, 8, 12, 12]), xa)
+    tb = B.TensorData("b_in", B.DataTypeFloat32, B.Shape([2, 16, 12, 12]), xb)
+    outs = [B.OutputConfig("y", Shape=[2, 24, 1, 1], DataType="FLOAT32")]
+    mgr.LoadModel("mini_two_input")
+    try:
+        m = mgr.GetModel("mini_two_input")
+        assert m.GetMetadata().Inputs == ["b_in", "a_in"]
+        y_ab = m.Infer([ta, tb], outs)[0].Data.copy()
+        y_ba = m.Infer([tb, ta], outs)[0].Data.copy()
+        np.testing.assert_array_equal(y_ab, y_ba)
+        assert rel_err(y_ab.reshape(g.shape), g) < RTOL
+        yo = O.run(O.load_model(models.two_input_graph(2)), {"a_in": xa, "b_in": xb})["y"]
+        assert rel_err(y_ab.reshape(yo.shape), yo) < RTOL
+        with pytest.raises(RuntimeError, match="Expected 2 inputs, got 1"):
+            m.Infer([ta], outs)
+        with pytest.raises(RuntimeError, match="Required input tensor not provided: b_in"):
+            m.Infer([ta, ta], outs)
+        # swapped payloads under the right names are a shape error, not a silent mix-up
+        bad_a = B.TensorData("a_in", B.DataTypeFloat32, B.Shape([2, 16, 12, 12]), xb)
+        bad_b = B.TensorData("b_in", B.DataTypeFloat32, B.Shape([2, 8, 12, 12]), xa)
+        with pytest.raises(RuntimeError, match="Got invalid dimensions for input"):
+            m.Infer([bad_a, bad_b], outs)
+    finally:
+        mgr.UnloadModel("mini_two_input")

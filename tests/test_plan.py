@@ -170,3 +170,50 @@ def test_resnet50_plan_fuses_shortcuts(tmp_path):
     # projection blocks: the Add rides on the projection conv (its partner branch is complete by then), 4 of them strided or not
     assert sum(1 for s in res if "proj" in s["name"]) == 4
     assert abs(p["total_flops"] / 32 / 8.18e9 - 1) < 1e-2
+
+
+def test_bn_after_absorbed_residual_is_not_folded_into_the_conv(tmp_path):
+    """Pre-activation blocks: Conv -> Add -> BN -> [ReLU] -> GAP.  Folding that BN into the conv's weights/bias would leave the
+    shortcut operand unscaled (relu(s*conv + s*b + t + res) instead of relu(s*(conv+res) + t)); the planner must stop epilogue
+    fusion at the residual and hand the BN to the consumer's prologue."""
+    for final_relu in (True, False):
+        path = models.write_repo(str(tmp_path), f"preact{int(final_relu)}", models.preact_block(2, final_relu=final_relu))
+        steps = B.DescribeModel(path, 2)["plan"]["steps"]
+        res = [s for s in steps if s["kind"] == "conv" and s["residual"]]
+        assert len(res) == 2
+        for s in res:
+            assert "bn" not in s["name"].split("conv")[-1], s["name"]       # nothing BN-ish after the Add in the fused name
+            assert not s["relu"]
+        last = steps[-1]
+        assert last["kind"] == "gap" and last["pre"] and last["pre_relu"] == final_relu and "bn" in last["name"]
+        # the BN between the blocks has two readers of its input (next BN and next Add): it rides on the consumer conv
+        assert sum(1 for s in steps if s["kind"] == "eltwise") == 0
+
+
+def test_caffe_scale_export_forms_plan_identically(tmp_path):
+    """[C,1,1] constants, [C] constants through Unsqueeze nodes, and opset-6 broadcast=1/axis=1: three spellings of the same
+    Scale layer that must all fold into the neighbouring convs; none may reach the device as a separate step."""
+    shapes = {}
+    for form in (True, "unsqueeze", "legacy_axis"):
+        mb = models.densenet(3, growth=12, blocks=(2, 2, 2), stem=24, image=64, classes=17, seed=6, caffe_scale=form)
+        path = models.write_repo(str(tmp_path), f"scale_{form}", mb)
+        d = B.DescribeModel(path, 3)
+        assert d["opset"] == (6 if form == "legacy_axis" else 11)
+        steps = d["plan"]["steps"]
+        assert all(s["kind"] in ("conv", "pool", "gap") for s in steps)
+        shapes[form] = [(s["kind"], s["k"], s["in"]["c"], s["out"]["c"], s["pre"], s["pre_relu"], s["relu"], s["bias"]) for s in steps]
+    assert shapes[True] == shapes["unsqueeze"] == shapes["legacy_axis"]
+    # opset-6 Mul without broadcast=1 against a differently shaped constant is an error, as in the operator's definition
+    gb = models.GraphBuilder("bad", 1)
+    y = gb.simple("Mul", ["x", gb.init("s", np.ones(4, np.float32))], out="y")
+    f = tmp_path / "bad_legacy.onnx"
+    f.write_bytes(gb.finish([("x", [1, 4, 2, 2])], [("y", [1, 4, 2, 2])], opset=6))
+    with pytest.raises(RuntimeError, match="broadcast attribute is not set"):
+        B.DescribeModel(str(f), 1)
+
+
+def test_two_input_graph_plan(tmp_path):
+    path = models.write_repo(str(tmp_path), "two", models.two_input_graph("N"))
+    d = B.DescribeModel(path, 4)
+    assert [i["name"] for i in d["inputs"]] == ["b_in", "a_in"]            # graph order, not alphabetical
+    assert [i["dims"] for i in d["plan"]["inputs"]] == [[4, 16, 12, 12], [4, 8, 12, 12]]
