@@ -69,7 +69,7 @@ ABI_SYMBOLS = [
     "ModelLoad", "ModelUnload",
 ]
 EXT_SYMBOLS = ["EngineDescribeModel", "EnginePrepare", "EngineRunPrepared", "EngineSynchronize", "EngineGetStream",
-               "EngineProfile", "EngineGetWeightBlob", "EngineWeightsUpdated", "EngineGetPrecision", "EngineMemcpy", "EngineMfmaPeak", "EngineGetBatcherStats", "EngineGetShardStats", "EngineVectorAdd"]
+               "EngineProfile", "EngineGetWeightBlob", "EngineWeightsUpdated", "EngineGetPrecision", "EngineMemcpy", "EngineMfmaPeak", "EngineGetBatcherStats", "EngineGetShardStats", "EngineGetRuntimeInfo", "EngineVectorAdd"]
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -116,6 +116,7 @@ def lib() -> C.CDLL:
             "EngineMfmaPeak": (C.c_double, [C.c_int, C.c_int, C.c_int]),
             "EngineGetBatcherStats": (C.c_bool, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
             "EngineGetShardStats": (C.c_bool, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
+            "EngineGetRuntimeInfo": (C.c_void_p, [vp, C.c_int, C.POINTER(C.c_void_p)]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)   # AttributeError here = symbol missing from the .so
@@ -514,6 +515,19 @@ def ShardStats(model: Model) -> tuple:
     if not lib().EngineGetShardStats(model.handle, C.byref(n), C.byref(calls)):
         raise RuntimeError("shard stats unavailable")
     return int(n.value), int(calls.value)
+
+
+def RuntimeInfo(model: Model, checksums: bool = False) -> dict:
+    """Lanes, shards, RCCL broadcast facts, device-time accounting and pipelined-path counters of a loaded model (EngineGetRuntimeInfo)."""
+    import json
+    err = C.c_void_p()
+    p = lib().EngineGetRuntimeInfo(model.handle, 1 if checksums else 0, C.byref(err))
+    if not p:
+        raise RuntimeError(_take_error(err))
+    try:
+        return json.loads(C.string_at(p).decode())
+    finally:
+        lib().FreeErrorMessage(p)
 
 
 def CopyToDevice(model: Model, dst_dev: int, src: np.ndarray) -> None:

@@ -22,7 +22,7 @@ LIB = os.path.join(PKG, "lib", "libinference_engine.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-SOURCES = ["onnx_reader.cpp", "plan.cpp", "repository.cpp", "executor.cpp", "bridge.cpp", "kernels.hip", "kernels_f16.hip", "kernels_ws.hip", "kernels_ws32.hip", "kernels_stem.hip", "kernels_direct.hip"]
+SOURCES = ["onnx_reader.cpp", "plan.cpp", "repository.cpp", "config.cpp", "executor.cpp", "bridge.cpp", "kernels.hip", "kernels_f16.hip", "kernels_ws.hip", "kernels_ws32.hip", "kernels_stem.hip", "kernels_direct.hip"]
 COMMON = ["-std=c++17", "-O3", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter", "-Wno-unused-result",
           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
@@ -63,7 +63,8 @@ def build_library(force: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(lambda s: _compile(s, force), SOURCES))
     if force or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", *objs, "-o", LIB, "-lstdc++fs", "-lpthread"]
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", *objs, "-o", LIB, "-lstdc++fs", "-lpthread",
+               "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

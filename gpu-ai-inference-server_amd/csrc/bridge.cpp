@@ -16,7 +16,8 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
-#include <regex>
+#include <functional>
+#include <shared_mutex>
 #include <cstdlib>
 #include <cstring>
 #include <filesystem>
@@ -32,6 +33,9 @@
 
 #include "../../include/inference_bridge.h"
 #include "../../include/inference_engine_ext.h"
+#include <rccl/rccl.h>
+
+#include "config.h"
 #include "executor.h"
 #include "kernels.h"
 #include "onnx_reader.h"
@@ -83,6 +87,105 @@ void set_error(ErrorMessage* error, const std::string& msg) {
     if (error) *error = dup_cstr(msg);
 }
 
+// A model's execution lanes (ie::DeviceModel objects) are used by one host thread at a time.  Requests that run on ONE lane take any
+// free one (config.json "instance_count" lanes on the primary device + the shard replicas); a sharded request takes the first
+// `n` lanes together and waits for them to drain first.
+struct LanePool {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<char> busy;
+    int exclusive_waiters = 0;
+    int in_flight = 0, max_in_flight = 0;
+    void Reset(size_t n) { std::lock_guard<std::mutex> g(mu); busy.assign(n, 0); exclusive_waiters = 0; in_flight = 0; }
+    // prefer the highest-numbered free lane: extra lanes first, so lane 0 (EnginePrepare / EngineRunPrepared) stays free longest
+    int AcquireAny() {
+        std::unique_lock<std::mutex> lk(mu);
+        int k = -1;
+        cv.wait(lk, [&] {
+            if (exclusive_waiters > 0 || busy.empty()) return busy.empty();
+            for (int i = int(busy.size()) - 1; i >= 0; --i) if (!busy[size_t(i)]) { k = i; return true; }
+            return false;
+        });
+        if (k < 0) return -1;
+        busy[size_t(k)] = 1;
+        max_in_flight = std::max(max_in_flight, ++in_flight);
+        return k;
+    }
+    void AcquireOne(int k) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return size_t(k) < busy.size() && !busy[size_t(k)]; });
+        busy[size_t(k)] = 1;
+        max_in_flight = std::max(max_in_flight, ++in_flight);
+    }
+    void AcquireRange(int n) {
+        std::unique_lock<std::mutex> lk(mu);
+        ++exclusive_waiters;
+        cv.wait(lk, [&] { for (int i = 0; i < n; ++i) if (busy[size_t(i)]) return false; return true; });
+        --exclusive_waiters;
+        for (int i = 0; i < n; ++i) busy[size_t(i)] = 1;
+        max_in_flight = std::max(max_in_flight, ++in_flight);
+    }
+    void Release(int first, int n) {
+        { std::lock_guard<std::mutex> g(mu); for (int i = first; i < first + n; ++i) busy[size_t(i)] = 0; --in_flight; }
+        cv.notify_all();
+    }
+};
+
+// Persistent helper threads, one per shard replica: a sharded ModelInfer hands slice k to thread k-1 and runs slice 0 itself.
+// (Round 1 spawned and joined std::threads per call; at 4 images per GPU that churn was a first-order cost.)
+class WorkerPool {
+public:
+    ~WorkerPool() { Stop(); }
+    void Start(int n) {
+        Stop();
+        for (int i = 0; i < n; ++i) {
+            ws_.push_back(std::make_unique<W>());
+            W* w = ws_.back().get();
+            w->th = std::thread([this, w] {
+                for (;;) {
+                    std::function<void()> job;
+                    {
+                        std::unique_lock<std::mutex> lk(w->mu);
+                        w->cv.wait(lk, [&] { return w->stop || w->has; });
+                        if (w->stop) return;
+                        job = std::move(w->job);
+                        w->has = false;
+                    }
+                    job();
+                    { std::lock_guard<std::mutex> g(dmu_); --pending_; }
+                    dcv_.notify_all();
+                }
+            });
+        }
+    }
+    void Stop() {
+        for (auto& w : ws_) { { std::lock_guard<std::mutex> g(w->mu); w->stop = true; } w->cv.notify_all(); }
+        for (auto& w : ws_) if (w->th.joinable()) w->th.join();
+        ws_.clear();
+    }
+    size_t size() const { return ws_.size(); }
+    void Submit(size_t k, std::function<void()> fn) {
+        { std::lock_guard<std::mutex> g(dmu_); ++pending_; }
+        W* w = ws_.at(k).get();
+        { std::lock_guard<std::mutex> g(w->mu); w->job = std::move(fn); w->has = true; }
+        w->cv.notify_one();
+    }
+    void Wait() { std::unique_lock<std::mutex> lk(dmu_); dcv_.wait(lk, [&] { return pending_ == 0; }); }
+private:
+    struct W { std::thread th; std::mutex mu; std::condition_variable cv; std::function<void()> job; bool has = false, stop = false; };
+    std::vector<std::unique_ptr<W>> ws_;
+    std::mutex dmu_;
+    std::condition_variable dcv_;
+    int pending_ = 0;
+};
+
+uint64_t fnv1a64(const void* data, size_t n) {
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+}
+
 struct ModelObj {
     std::string path;
     ModelType type = MODEL_UNKNOWN;
@@ -91,22 +194,35 @@ struct ModelObj {
     std::string name, version;
     std::vector<std::string> input_names, output_names;   // config names until Load replaces them with the graph's
 
-    std::mutex mu;                 // serialises Load / Unload / Infer on this model
+    std::shared_mutex life;        // Load / Unload exclusive; everything that touches the lanes holds it shared
     std::atomic<bool> loaded{false};
+    std::mutex err_mu;
     std::string last_error;
+    void SetError(const std::string& m) { std::lock_guard<std::mutex> g(err_mu); last_error = m; }
+    std::string GetError() { std::lock_guard<std::mutex> g(err_mu); return last_error; }
     std::shared_ptr<const ie::OnnxModel> onnx;
     ie::ModelInfo info;
-    std::unique_ptr<ie::DeviceModel> dev;
-    // In-process batch sharding (single process, all GPUs of the node): extra replicas of the model on other devices.
-    // A request's rows are cut into contiguous slices, one per replica, run concurrently (one host thread per replica), and the
-    // result rows land at their offsets of the caller's output buffers.  IE_GPUS=<n> / config.json "gpus": n (devices
-    // device_id .. device_id+n-1) or IE_SHARD_DEVICES=<id,id,...> (explicit list; ids may repeat, which is how the single-GPU
-    // tests exercise the sharding logic).  Every replica uploads the packed weights itself (32 MB over PCIe, once, at load).
-    std::vector<std::unique_ptr<ie::DeviceModel>> replicas;     // replicas[k] serves slice k+1 (slice 0 is `dev`)
+    ie::EngineConfig cfg;          // config.json, parsed once at load
+    // Execution lanes.  lanes[0] is the primary.  lanes[1 .. num_shards) are the shard replicas of the in-process batch sharding
+    // (single process, all GPUs of the node; IE_GPUS=<n> / config.json "gpus": n -> devices device_id .. device_id+n-1, or
+    // IE_SHARD_DEVICES=<id,id,...>, ids may repeat, which is how the single-GPU tests exercise the logic).  lanes[num_shards ..) are
+    // extra lanes on the primary device (config.json / ModelConfig "instance_count"): concurrent requests run side by side.
+    // A replica on another device owns its weights and receives the packed blob by ONE ncclBroadcast at load; lanes on a device that
+    // already holds the blob share it.
+    std::vector<std::unique_ptr<ie::DeviceModel>> lanes;
+    int num_shards = 1;
+    LanePool pool;
+    WorkerPool workers;
+    struct RcclInfo { bool used = false; int ranks = 0; size_t bytes = 0; double init_ms = 0, bcast_ms = 0; int owners = 1; } rccl;
     float u8_scale = 1.0f / 255.0f, u8_bias = 0.0f;
     int64_t load_time_ns = 0;
     std::atomic<int64_t> inference_count{0}, total_ns{0}, last_ns{0};
     std::atomic<size_t> memory_usage_bytes{0};
+    // device-side accounting for the observability string (ModelGetMetadata.description): HIP-event time of the forwards and the
+    // planner's algorithmic FLOPs / bytes of what ran
+    std::mutex acct_mu;
+    double acct_ms = 0, acct_flops = 0, acct_bytes = 0;
+    int64_t acct_forwards = 0, acct_images = 0;
 
     // ---- dynamic request batcher: honours the reference's inert max_batch_size / dynamic_batching fields
     // (model.h:63,70-71).  Concurrent ModelInfer calls (one per gin goroutine) are coalesced into ONE device batch and the
@@ -124,6 +240,7 @@ struct ModelObj {
         std::string err;
     };
     int cfg_max_batch = 0;        // from ModelCreate's ModelConfig {dynamic_batching, max_batch_size}
+    int cfg_instances = 0;        // from ModelCreate's ModelConfig.instance_count
     int max_batch = 0;            // 0/1 = batching off
     int batch_window_us = 200;
     bool batchable = false;       // set at Load: symbolic batch axis on every graph input and output
@@ -135,149 +252,246 @@ struct ModelObj {
 
     bool Load();      // model.cpp:503-548 + 825-871
     void Unload();    // model.cpp:618-648
-    void Execute(std::vector<Pending*>& batch);   // runs one device batch for these callers (takes `mu`)
+    void Execute(std::vector<Pending*>& batch);   // runs one device batch for these callers
     void RunBatched(Pending& req);                // leader/follower coalescing
+    void BroadcastWeights();                      // RCCL: primary's packed blob -> every other weight owner
+    void Account(ie::DeviceModel& d, const ie::PlanInstance& pi);
+    using Segs = std::pair<std::vector<std::vector<ie::DeviceModel::InSeg>>, std::vector<std::vector<ie::DeviceModel::OutSeg>>>;
+    const ie::PlanInstance* RunOnLanes(const std::vector<std::vector<int64_t>>& shapes, int64_t rows, bool allow_shard, const Segs& segs, bool* sharded);
 };
 
+#define NCCL_OK(call)                                                                                             \
+    do {                                                                                                          \
+        ncclResult_t r_ = (call);                                                                                 \
+        if (r_ != ncclSuccess) throw std::runtime_error(std::string("RCCL error in " #call ": ") + ncclGetErrorString(r_)); \
+    } while (0)
+
+// One communicator per distinct device (ncclCommInitAll, single process), one in-place ncclBroadcast of the packed fp32 blob from
+// the primary to every other device's owner inside a group call, then each receiver rebuilds its derived mirrors.  This is the
+// only collective of the whole path; nothing is exchanged per inference.  The reference has no counterpart: it
+// hard-codes device 0 (inference_bridge.cpp:346-347).
+void ModelObj::BroadcastWeights() {
+    std::vector<ie::DeviceModel*> owners;          // lanes that own a weight allocation of their own, primary first
+    for (auto& l : lanes) {
+        bool first = true;
+        for (auto* o : owners) if (o->shared_weights() == l->shared_weights()) first = false;
+        if (first) owners.push_back(l.get());
+    }
+    rccl.owners = int(owners.size());
+    if (owners.size() < 2) return;
+    std::vector<int> devs;                         // distinct devices, the primary's first = rank 0 = root
+    std::vector<ie::DeviceModel*> rank_owner;
+    for (auto* o : owners)
+        if (std::find(devs.begin(), devs.end(), o->device()) == devs.end()) { devs.push_back(o->device()); rank_owner.push_back(o); }
+    const size_t count = owners[0]->weight_bytes() / sizeof(float);
+    std::vector<ncclComm_t> comms(devs.size(), nullptr);
+    auto t0 = std::chrono::steady_clock::now();
+    NCCL_OK(ncclCommInitAll(comms.data(), int(devs.size()), devs.data()));
+    auto t1 = std::chrono::steady_clock::now();
+    try {
+        if (devs.size() > 1) {
+            NCCL_OK(ncclGroupStart());
+            for (size_t r = 0; r < devs.size(); ++r) {
+                if (hipSetDevice(devs[r]) != hipSuccess) throw std::runtime_error("hipSetDevice failed during the weight broadcast");
+                NCCL_OK(ncclBroadcast(rank_owner[r]->weights(), rank_owner[r]->weights(), count, ncclFloat, 0, comms[r], rank_owner[r]->stream()));
+            }
+            NCCL_OK(ncclGroupEnd());
+            for (auto* o : rank_owner) o->Synchronize();
+        }
+        // further owners on a device that already holds the blob (IE_SHARD_PRIVATE_WEIGHTS=1, how the one-GPU box moves real bytes
+        // through RCCL): with one rank an out-of-place broadcast copies send -> recv; with more ranks a device-to-device copy does
+        for (auto* o : owners) {
+            if (std::find(rank_owner.begin(), rank_owner.end(), o) != rank_owner.end()) continue;
+            const size_t r = size_t(std::find(devs.begin(), devs.end(), o->device()) - devs.begin());
+            if (hipSetDevice(devs[r]) != hipSuccess) throw std::runtime_error("hipSetDevice failed during the weight broadcast");
+            if (devs.size() == 1) NCCL_OK(ncclBroadcast(rank_owner[r]->weights(), o->weights(), count, ncclFloat, 0, comms[r], o->stream()));
+            else if (hipMemcpyAsync(o->weights(), rank_owner[r]->weights(), count * sizeof(float), hipMemcpyDeviceToDevice, o->stream()) != hipSuccess)
+                throw std::runtime_error("device-to-device weight copy failed");
+            o->Synchronize();
+        }
+    } catch (...) {
+        for (auto c : comms) if (c) (void)ncclCommDestroy(c);
+        throw;
+    }
+    auto t2 = std::chrono::steady_clock::now();
+    for (auto c : comms) if (c) (void)ncclCommDestroy(c);
+    for (size_t i = 1; i < owners.size(); ++i) owners[i]->WeightsArrived();
+    (void)hipSetDevice(device_id);
+    rccl.used = true;
+    rccl.ranks = int(devs.size());
+    rccl.bytes = count * sizeof(float);
+    rccl.init_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    rccl.bcast_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
+}
+
 bool ModelObj::Load() {
-    std::lock_guard<std::mutex> g(mu);
+    std::unique_lock<std::shared_mutex> g(life);
     auto t0 = std::chrono::steady_clock::now();
     std::error_code ec;
     if (!std::filesystem::exists(path, ec)) {
-        last_error = "Model file not found: " + path;
+        SetError("Model file not found: " + path);
         return false;
     }
     bool ok = false;
     switch (type) {
-        case MODEL_TENSORFLOW: last_error = "TensorFlow model loading not implemented"; break;
-        case MODEL_TENSORRT: last_error = "TensorRT model loading not implemented"; break;
-        case MODEL_PYTORCH: last_error = "PyTorch model loading not implemented"; break;
-        case MODEL_CUSTOM: last_error = "Custom model loading not implemented"; break;
+        case MODEL_TENSORFLOW: SetError("TensorFlow model loading not implemented"); break;
+        case MODEL_TENSORRT: SetError("TensorRT model loading not implemented"); break;
+        case MODEL_PYTORCH: SetError("PyTorch model loading not implemented"); break;
+        case MODEL_CUSTOM: SetError("Custom model loading not implemented"); break;
         case MODEL_ONNX: {
             try {
                 const std::string file = path + "/model.onnx";
                 if (!std::filesystem::exists(file, ec)) {
-                    last_error = "ONNX model file not found: " + file;
+                    SetError("ONNX model file not found: " + file);
                     break;
                 }
                 if (device != DEVICE_GPU) {
-                    last_error = "DEVICE_CPU execution is not provided by the MI355X engine (a HIP device is required)";
+                    SetError("DEVICE_CPU execution is not provided by the MI355X engine (a HIP device is required)");
                     break;
                 }
                 auto parsed = std::make_shared<ie::OnnxModel>(ie::LoadOnnxFile(file));
                 ie::ModelInfo inf = ie::DescribeModel(*parsed);
+                ie::EngineConfig conf = ie::LoadEngineConfig(path);       // read ONCE; a malformed file is a load error
                 // Precision: IE_PRECISION=fp16|fp32, else config.json {"precision": "fp16"}; default fp32 (the reference's
                 // ONNX Runtime session computes in the model's own fp32).
                 ie::Precision prec = ie::Precision::F32;
                 {
-                    std::string want;
+                    std::string want = conf.precision;
                     if (const char* e = std::getenv("IE_PRECISION")) want = e;
-                    else {
-                        std::ifstream cf(path + "/config.json");
-                        if (cf) {
-                            std::stringstream ss; ss << cf.rdbuf();
-                            const std::string txt = ss.str();
-                            std::smatch mm;
-                            if (std::regex_search(txt, mm, std::regex("\"precision\"\\s*:\\s*\"([A-Za-z0-9]+)\""))) want = mm[1];
-                        }
-                    }
                     for (auto& ch : want) ch = char(std::tolower(static_cast<unsigned char>(ch)));
                     if (want == "fp16" || want == "f16" || want == "half" || want == "float16") prec = ie::Precision::F16;
                     else if (!want.empty() && want != "fp32" && want != "f32" && want != "float32" && want != "float") {
-                        last_error = "ONNX model loading error: unsupported precision '" + want + "' (fp32 or fp16)";
+                        SetError("ONNX model loading error: unsupported precision '" + want + "' (fp32 or fp16)");
                         break;
                     }
                 }
-                auto dm = std::make_unique<ie::DeviceModel>(parsed, device_id, prec);
-                {   // UINT8 ingest transform x * scale + bias: config.json "uint8_scale" / "uint8_bias" (default 1/255, 0: the reference
-                    // client's /255 convention, client/test_client.py:189)
-                    std::ifstream cf(path + "/config.json");
-                    if (cf) {
-                        std::stringstream ss; ss << cf.rdbuf();
-                        const std::string txt = ss.str();
-                        std::smatch mm;
-                        float sc = 1.0f / 255.0f, bi = 0.0f;
-                        const std::string num = "(-?[0-9]*\\.?[0-9]+(?:[eE][-+]?[0-9]+)?)";
-                        if (std::regex_search(txt, mm, std::regex("\"uint8_scale\"\\s*:\\s*" + num))) sc = std::stof(mm[1]);
-                        if (std::regex_search(txt, mm, std::regex("\"uint8_bias\"\\s*:\\s*" + num))) bi = std::stof(mm[1]);
-                        dm->SetU8Transform(sc, bi);
-                        u8_scale = sc; u8_bias = bi;
-                    }
-                }
-                // Plan once at load (symbolic dims -> 1): rejects unsupported graphs here, like Ort::Session's
-                // constructor does, and puts the packed weights into HBM.
+                // UINT8 ingest transform x * scale + bias: config.json "uint8_scale" / "uint8_bias" (default 1/255, 0: the reference
+                // client's /255 convention, client/test_client.py:189)
+                u8_scale = conf.uint8_scale;
+                u8_bias = conf.uint8_bias;
+                ie::DeviceModelOptions opt;
+                opt.precision = prec;
+                opt.tune_cache_path = path + "/.ie_tune." + (prec == ie::Precision::F16 ? "fp16" : "fp32") + ".txt";
+                auto primary = std::make_unique<ie::DeviceModel>(parsed, device_id, opt);
+                primary->SetU8Transform(u8_scale, u8_bias);
+                // Plan + tune at load, off the request path (like Ort::Session's constructor, which also rejects unsupported graphs
+                // here): the config's declared shape (symbolic dims -> 1) and every batch size of "tune_batches" / IE_TUNE_BATCHES.
                 std::vector<std::vector<int64_t>> shapes;
-                for (auto& vi : inf.inputs) {
-                    std::vector<int64_t> s = vi.dims;
-                    for (auto& d : s) if (d <= 0) d = 1;
+                for (size_t i = 0; i < inf.inputs.size(); ++i) {
+                    std::vector<int64_t> s = inf.inputs[i].dims;
+                    int64_t cfg_batch = 1;
+                    for (const auto& ic : conf.inputs)
+                        if (ic.name == inf.inputs[i].name && ic.shape.size() == s.size() && !ic.shape.empty() && ic.shape[0] > 0) cfg_batch = ic.shape[0];
+                    for (size_t k = 0; k < s.size(); ++k) if (s[k] <= 0) s[k] = (k == 0 ? cfg_batch : 1);
                     shapes.push_back(s);
                 }
-                dm->Prepare(shapes);
-                std::vector<std::unique_ptr<ie::DeviceModel>> reps;
+                primary->Prepare(shapes, true);
+                bool symbolic_batch = !inf.inputs.empty();
+                for (auto& vi : inf.inputs) if (vi.dims.empty() || vi.dims[0] > 0) symbolic_batch = false;
+                for (auto& vi : inf.outputs) if (vi.dims.empty() || vi.dims[0] > 0) symbolic_batch = false;
                 {
-                    std::vector<int> ids;
-                    if (const char* e = std::getenv("IE_SHARD_DEVICES")) {
+                    std::vector<int64_t> tb = conf.tune_batches;
+                    if (const char* e = std::getenv("IE_TUNE_BATCHES")) {
+                        tb.clear();
                         std::stringstream ss(e);
                         std::string tok;
-                        while (std::getline(ss, tok, ',')) if (!tok.empty()) ids.push_back(std::atoi(tok.c_str()));
-                        if (!ids.empty()) ids.erase(ids.begin());           // the first id is the primary device's slice
-                    } else {
-                        int n = 1;
-                        if (const char* e = std::getenv("IE_GPUS")) n = std::atoi(e);
-                        else {
-                            std::ifstream cf(path + "/config.json");
-                            if (cf) {
-                                std::stringstream ss; ss << cf.rdbuf();
-                                const std::string txt = ss.str();
-                                std::smatch mm;
-                                if (std::regex_search(txt, mm, std::regex("\"gpus\"\\s*:\\s*(\\d+)"))) n = std::stoi(mm[1]);
-                            }
-                        }
-                        const int have = ie::HipDeviceCount();
-                        for (int k = 1; k < n && device_id + k < have; ++k) ids.push_back(device_id + k);
+                        while (std::getline(ss, tok, ',')) if (!tok.empty()) tb.push_back(std::atoll(tok.c_str()));
                     }
-                    for (int id : ids) {
-                        auto r = std::make_unique<ie::DeviceModel>(parsed, id, prec);
-                        r->SetU8Transform(u8_scale, u8_bias);
-                        r->Prepare(shapes);
-                        reps.push_back(std::move(r));
+                    for (int64_t b : tb) {
+                        if (!symbolic_batch || b <= 0 || b > 65536) continue;
+                        std::vector<std::vector<int64_t>> sh = shapes;
+                        for (auto& s : sh) s[0] = b;
+                        primary->Prepare(sh, true);
                     }
                 }
+                // ---- shard replicas and extra lanes ----
+                std::vector<int> shard_ids;                       // devices of lanes[1 .. num_shards)
+                if (const char* e = std::getenv("IE_SHARD_DEVICES")) {
+                    std::stringstream ss(e);
+                    std::string tok;
+                    while (std::getline(ss, tok, ',')) if (!tok.empty()) shard_ids.push_back(std::atoi(tok.c_str()));
+                    if (!shard_ids.empty()) shard_ids.erase(shard_ids.begin());           // the first id is the primary's slice
+                } else {
+                    int n = conf.gpus > 0 ? conf.gpus : 1;
+                    if (const char* e = std::getenv("IE_GPUS")) n = std::atoi(e);
+                    const int have = ie::HipDeviceCount();
+                    for (int k = 1; k < n && device_id + k < have; ++k) shard_ids.push_back(device_id + k);
+                }
+                if (!symbolic_batch) shard_ids.clear();           // a fixed-batch graph cannot be sliced
+                int instances = conf.instance_count > 0 ? conf.instance_count : (cfg_instances > 0 ? cfg_instances : 1);
+                if (const char* e = std::getenv("IE_INSTANCES")) instances = std::atoi(e);
+                instances = std::max(1, std::min(instances, 16));
+                const bool private_weights = [] { const char* e = std::getenv("IE_SHARD_PRIVATE_WEIGHTS"); return e && e[0] == '1'; }();
+                std::vector<std::unique_ptr<ie::DeviceModel>> built;
+                built.push_back(std::move(primary));
+                struct Spec { int dev; bool shard; };
+                std::vector<Spec> specs;
+                for (int id : shard_ids) specs.push_back({id, true});
+                for (int k = 1; k < instances; ++k) specs.push_back({device_id, false});
+                // constructors run here (they decide who shares whose weights); planning, allocation and graph capture of the
+                // replicas then run in parallel on the shard worker threads
+                for (const Spec& sp : specs) {
+                    ie::DeviceModelOptions o = opt;
+                    o.tune_cache_path.clear();
+                    ie::DeviceModel* holder = nullptr;
+                    if (!(sp.shard && private_weights))
+                        for (auto& l : built) if (l->device() == sp.dev) { holder = l.get(); break; }
+                    if (holder) o.share = holder->shared_weights();
+                    else o.upload_weights = false;                                    // filled by the RCCL broadcast below
+                    auto r = std::make_unique<ie::DeviceModel>(parsed, sp.dev, o);
+                    r->SetU8Transform(u8_scale, u8_bias);
+                    if (!holder) {                                                    // same hardware: adopt the primary's kernel choices
+                        auto& src = *built[0]->shared_weights();
+                        auto& dst = *r->shared_weights();
+                        std::lock_guard<std::mutex> g1(src.tune_mu);
+                        dst.tune_cache = src.tune_cache;
+                    }
+                    built.push_back(std::move(r));
+                }
+                workers.Start(int(shard_ids.size()));
+                if (built.size() > 1) {
+                    std::vector<std::string> errs(built.size());
+                    WorkerPool builders;
+                    builders.Start(int(built.size()) - 1);
+                    for (size_t k = 1; k < built.size(); ++k)
+                        builders.Submit(k - 1, [&, k] {
+                            try { built[k]->Prepare(shapes, false); } catch (const std::exception& e) { errs[k] = e.what(); }
+                        });
+                    builders.Wait();
+                    builders.Stop();
+                    for (auto& e : errs) if (!e.empty()) throw std::runtime_error(e);
+                }
+                lanes = std::move(built);
+                num_shards = int(shard_ids.size()) + 1;
+                rccl = RcclInfo();
+                BroadcastWeights();
+                pool.Reset(lanes.size());
                 input_names.clear();
                 output_names.clear();
                 for (auto& vi : inf.inputs) input_names.push_back(vi.name);
                 for (auto& vi : inf.outputs) output_names.push_back(vi.name);
                 memory_usage_bytes = inf.memory_usage_bytes;   // reference's estimate formula, model.cpp:979-1035
-                batchable = !inf.inputs.empty();
-                for (auto& vi : inf.inputs) if (vi.dims.empty() || vi.dims[0] > 0) batchable = false;
-                for (auto& vi : inf.outputs) if (vi.dims.empty() || vi.dims[0] > 0) batchable = false;
-                {   // batching knobs: environment first, then the two config.json keys the reference carries but never reads
+                batchable = symbolic_batch;
+                {   // batching knobs: environment first, then config.json, then ModelCreate's ModelConfig
                     max_batch = cfg_max_batch;
+                    if (conf.dynamic_batching && conf.max_batch_size > 1) max_batch = conf.max_batch_size;
                     if (const char* e = std::getenv("IE_DYNAMIC_BATCH")) max_batch = std::atoi(e);
-                    else {
-                        std::ifstream cf(path + "/config.json");
-                        if (cf) {
-                            std::stringstream ss; ss << cf.rdbuf();
-                            const std::string txt = ss.str();
-                            std::smatch mm;
-                            const bool dyn = std::regex_search(txt, std::regex("\"dynamic_batching\"\\s*:\\s*true"));
-                            if (dyn && std::regex_search(txt, mm, std::regex("\"max_batch_size\"\\s*:\\s*(\\d+)"))) max_batch = std::stoi(mm[1]);
-                        }
-                    }
+                    if (conf.batch_window_us >= 0) batch_window_us = conf.batch_window_us;
                     if (const char* e = std::getenv("IE_BATCH_WINDOW_US")) batch_window_us = std::max(0, std::atoi(e));
                     if (max_batch > 4096) max_batch = 4096;
                 }
                 onnx = parsed;
                 info = std::move(inf);
-                dev = std::move(dm);
-                replicas = std::move(reps);
+                cfg = std::move(conf);
                 ok = true;
             } catch (const std::exception& e) {
-                last_error = std::string("ONNX model loading error: ") + e.what();
+                workers.Stop();
+                lanes.clear();
+                SetError(std::string("ONNX model loading error: ") + e.what());
             }
             break;
         }
-        default: last_error = "Unsupported model type"; return false;
+        default: SetError("Unsupported model type"); return false;
     }
     load_time_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
     loaded = ok;
@@ -285,9 +499,10 @@ bool ModelObj::Load() {
 }
 
 void ModelObj::Unload() {
-    std::lock_guard<std::mutex> g(mu);
-    replicas.clear();
-    dev.reset();
+    std::unique_lock<std::shared_mutex> g(life);      // waits for every in-flight ModelInfer (they hold it shared)
+    workers.Stop();
+    lanes.clear();
+    pool.Reset(0);
     onnx.reset();
     loaded = false;
 }
@@ -367,8 +582,7 @@ bool InferenceLoadModel(InferenceManagerHandle handle, const char* model_name, c
             handle->models[name] = obj;    // reserve the name; concurrent loaders of the same name now fail fast
         }
         if (!obj->Load()) {
-            std::string msg;
-            { std::lock_guard<std::mutex> g(obj->mu); msg = obj->last_error; }
+            const std::string msg = obj->GetError();
             std::lock_guard<std::mutex> g(handle->mu);
             handle->models.erase(name);
             set_error(error, msg);
@@ -437,6 +651,7 @@ ModelHandle ModelCreate(const char* model_path, ModelType type, const ModelConfi
         obj->name = config->name ? config->name : "";
         obj->version = config->version ? config->version : "1";
         if (config->dynamic_batching && config->max_batch_size > 1) obj->cfg_max_batch = config->max_batch_size;
+        if (config->instance_count > 1) obj->cfg_instances = config->instance_count;      // model.h:63: carried, never read, by the reference
         for (int i = 0; i < config->num_inputs; ++i)
             if (config->input_names && config->input_names[i]) obj->input_names.push_back(config->input_names[i]);
         for (int i = 0; i < config->num_outputs; ++i)
@@ -454,7 +669,7 @@ bool ModelLoad(ModelHandle handle, ErrorMessage* error) {
     if (!handle) { set_error(error, "Invalid model handle"); return false; }
     try {
         bool ok = handle->model->Load();
-        if (!ok) { std::lock_guard<std::mutex> g(handle->model->mu); set_error(error, handle->model->last_error); }
+        if (!ok) set_error(error, handle->model->GetError());
         return ok;
     } catch (const std::exception& e) { set_error(error, e.what()); return false; }
     catch (...) { set_error(error, "unknown error"); return false; }
@@ -482,9 +697,9 @@ bool ModelInfer(ModelHandle handle, const TensorData* inputs, int num_inputs, Te
         ModelObj::Pending req;
         bool batched = false;
         {
-            std::lock_guard<std::mutex> g(M.mu);
-            if (!M.loaded.load() || !M.dev) { set_error(error, "Model not loaded"); return false; }
-            auto failv = [&](const std::string& msg) { M.last_error = msg; set_error(error, msg); return false; };
+            std::shared_lock<std::shared_mutex> g(M.life);
+            if (!M.loaded.load() || M.lanes.empty()) { set_error(error, "Model not loaded"); return false; }
+            auto failv = [&](const std::string& msg) { M.SetError(msg); set_error(error, msg); return false; };
             // ---- ValidateInputs (model.cpp:734-794): count, then names ----
             const auto& gin = M.info.inputs;
             if (size_t(num_inputs) != gin.size())
@@ -543,7 +758,7 @@ bool ModelInfer(ModelHandle handle, const TensorData* inputs, int num_inputs, Te
         M.total_ns.fetch_add(ns);
         M.last_ns.store(ns);
         if (!req.ok) {
-            { std::lock_guard<std::mutex> g(M.mu); M.last_error = req.err; }
+            M.SetError(req.err);
             set_error(error, req.err);
             return false;
         }
@@ -571,92 +786,173 @@ void write_out_dims(TensorData* outputs, int num_outputs, const std::vector<ie::
     }
 }
 
+// Device-side accounting behind ModelGetMetadata.description: what ran (planner FLOPs / bytes) and how long the device took.
+void ModelObj::Account(ie::DeviceModel& d, const ie::PlanInstance& pi) {
+    const double ms = d.last_forward_ms();
+    if (ms <= 0) return;
+    std::lock_guard<std::mutex> g(acct_mu);
+    acct_ms += ms;
+    acct_flops += pi.plan.total_flops;
+    acct_bytes += pi.plan.total_bytes;
+    acct_forwards += 1;
+    acct_images += pi.plan.inputs.empty() || pi.plan.inputs[0].dims.empty() ? 0 : pi.plan.inputs[0].dims[0];
+}
+
+// Run one device batch described by gather/scatter segments over `rows` rows (rows == 0: the shapes are used as they are and the
+// batch cannot be cut).  One lane, or -- allow_shard, num_shards > 1 and at least one row per replica -- contiguous row slices on
+// all shard lanes at once (slice k on worker thread k-1, slice 0 on the calling thread).  Returns the plan instance that describes
+// the outputs (the caller holds `life` shared, so the pointer stays valid).
+const ie::PlanInstance* ModelObj::RunOnLanes(const std::vector<std::vector<int64_t>>& shapes, int64_t rows, bool allow_shard, const Segs& segs,
+                                             bool* sharded) {
+    const int S = num_shards;
+    *sharded = false;
+    if (!(allow_shard && S > 1 && rows >= S)) {
+        const int k = pool.AcquireAny();
+        if (k < 0) throw std::runtime_error("Model not loaded");
+        try {
+            ie::DeviceModel& D = *lanes[size_t(k)];
+            ie::PlanInstance& pi = D.Prepare(shapes, false);
+            D.InferHostSegments(pi, segs.first, segs.second);
+            Account(D, pi);
+            pool.Release(k, 1);
+            return &pi;
+        } catch (...) {
+            pool.Release(k, 1);
+            throw;
+        }
+    }
+    pool.AcquireRange(S);
+    std::vector<std::string> errs(static_cast<size_t>(S));
+    std::vector<ie::PlanInstance*> pis(static_cast<size_t>(S), nullptr);
+    auto run_slice = [&](int k) {
+        try {
+            ie::DeviceModel& D = *lanes[size_t(k)];
+            const int64_t r0 = rows * k / S, r1 = rows * (k + 1) / S, nr = r1 - r0;
+            std::vector<std::vector<int64_t>> sh = shapes;
+            for (auto& x : sh) x[0] = nr;
+            ie::PlanInstance& pi = D.Prepare(sh, false);
+            pis[size_t(k)] = &pi;
+            Segs mine;
+            mine.first.resize(segs.first.size());
+            mine.second.resize(segs.second.size());
+            for (size_t i = 0; i < segs.first.size() && i < pi.plan.inputs.size(); ++i) {
+                if (segs.first[i].empty()) continue;
+                const size_t row_bytes = size_t(pi.plan.inputs[i].view.numel() / nr) * (segs.first[i][0].u8 ? 1 : sizeof(float));
+                const size_t a = size_t(r0) * row_bytes, b = size_t(r1) * row_bytes;
+                for (const auto& sg : segs.first[i]) {
+                    const size_t lo = std::max(sg.dev_off, a), hi = std::min(sg.dev_off + sg.need, b);
+                    if (hi <= lo) continue;
+                    const size_t delta = lo - sg.dev_off;
+                    ie::DeviceModel::InSeg n2{sg.host ? static_cast<const char*>(sg.host) + delta : nullptr,
+                                              sg.have > delta ? std::min(sg.have - delta, hi - lo) : 0, hi - lo, lo - a, sg.u8};
+                    mine.first[i].push_back(n2);
+                }
+            }
+            for (size_t j = 0; j < segs.second.size() && j < pi.plan.outputs.size(); ++j) {
+                const size_t row_bytes = size_t(pi.plan.outputs[j].view.numel() / nr) * sizeof(float);
+                const size_t a = size_t(r0) * row_bytes, b = size_t(r1) * row_bytes;
+                for (const auto& sg : segs.second[j]) {
+                    const size_t nb = std::min(sg.cap, sg.need);
+                    const size_t lo = std::max(sg.dev_off, a), hi = std::min(sg.dev_off + nb, b);
+                    if (hi <= lo) continue;
+                    mine.second[j].push_back({static_cast<char*>(sg.host) + (lo - sg.dev_off), hi - lo, hi - lo, lo - a});
+                }
+            }
+            D.InferHostSegments(pi, mine.first, mine.second);
+            Account(D, pi);
+        } catch (const std::exception& e) {
+            errs[size_t(k)] = e.what();
+        } catch (...) {
+            errs[size_t(k)] = "unknown error";
+        }
+    };
+    for (int k = 1; k < S; ++k) workers.Submit(size_t(k - 1), [&run_slice, k] { run_slice(k); });
+    run_slice(0);
+    workers.Wait();
+    pool.Release(0, S);
+    for (auto& e : errs) if (!e.empty()) throw std::runtime_error(e);
+    // the slices wrote only the bytes they produced: zero-fill whatever a caller buffer has beyond its result
+    for (const auto& outs : segs.second)
+        for (const auto& sg : outs) {
+            const size_t nb = std::min(sg.cap, sg.need);
+            if (sg.cap > nb) std::memset(static_cast<char*>(sg.host) + nb, 0, sg.cap - nb);
+        }
+    *sharded = true;
+    return pis[0];
+}
+
 void ModelObj::Execute(std::vector<Pending*>& batch) {
-    std::lock_guard<std::mutex> g(mu);
+    std::shared_lock<std::shared_mutex> g(life);
     auto fail_all = [&](const std::string& msg) { for (auto* r : batch) { r->ok = false; r->err = msg; } };
-    if (!loaded.load() || !dev) { fail_all("Model not loaded"); return; }
+    if (!loaded.load() || lanes.empty()) { fail_all("Model not loaded"); return; }
     try {
-        if (batch.size() == 1 && !(batchable && max_batch > 1 && batch[0]->rows > 0) && !replicas.empty() && batchable) {
-            // ---- one request, rows sharded over the replicas (contiguous slices, like sharding.shard_batch) ----
+        const bool coalesced = !(batch.size() == 1 && !(batchable && max_batch > 1 && batch[0]->rows > 0));
+        const size_t nin = info.inputs.size(), nout = info.outputs.size();
+        Segs segs;
+        segs.first.resize(nin);
+        segs.second.resize(nout);
+        // elements per row of every graph input / output come from the request's own shapes (inputs) and the model (outputs are
+        // sized by the plan: the segment's `need` is clipped by InferHostSegments against the planned tensor)
+        auto row_elems = [](const std::vector<int64_t>& sh) { size_t n = 1; for (size_t k = 1; k < sh.size(); ++k) n *= size_t(sh[k]); return n; };
+        if (!coalesced) {
             Pending& r = *batch[0];
             const int64_t rows = r.shapes.empty() || r.shapes[0].empty() ? 0 : r.shapes[0][0];
-            bool same_rows = rows > 0;
+            bool same_rows = rows > 0 && batchable;
             for (auto& sh : r.shapes) if (sh.empty() || sh[0] != rows) same_rows = false;
-            const int S = int(replicas.size()) + 1;
-            if (same_rows && rows >= S) {
-                std::vector<std::string> errs;
-                errs.resize(size_t(S));
-                std::vector<ie::PlanInstance*> pis;
-                pis.resize(size_t(S), nullptr);
-                auto run_slice = [&](int k) {
-                    try {
-                        ie::DeviceModel& D = k == 0 ? *dev : *replicas[size_t(k - 1)];
-                        const int64_t r0 = rows * k / S, r1 = rows * (k + 1) / S, nr = r1 - r0;
-                        std::vector<std::vector<int64_t>> shapes = r.shapes;
-                        for (auto& sh : shapes) sh[0] = nr;
-                        ie::PlanInstance& pi = D.Prepare(shapes);
-                        pis[size_t(k)] = &pi;
-                        std::vector<const void*> in_ptr(r.in_ptr.size(), nullptr);
-                        std::vector<size_t> in_bytes(r.in_ptr.size(), 0);
-                        for (size_t i = 0; i < r.in_ptr.size(); ++i) {
-                            const size_t row_bytes = size_t(pi.plan.inputs[i].view.numel() / nr) * (r.in_u8[i] ? 1 : sizeof(float));
-                            const size_t off = size_t(r0) * row_bytes;
-                            if (r.in_ptr[i] && r.in_bytes[i] > off) {
-                                in_ptr[i] = static_cast<const char*>(r.in_ptr[i]) + off;
-                                in_bytes[i] = std::min(r.in_bytes[i] - off, size_t(nr) * row_bytes);
-                            }
-                        }
-                        std::vector<void*> out_ptr;
-                        std::vector<size_t> out_bytes;
-                        for (int j = 0; j < r.num_outputs; ++j) {
-                            void* p = nullptr;
-                            size_t nb = 0;
-                            const TensorData& o = r.outputs[j];
-                            if (size_t(j) < pi.plan.outputs.size() && o.data_type == DATATYPE_FLOAT32 && o.data && o.data_size > 0) {
-                                const size_t row_bytes = size_t(pi.plan.outputs[size_t(j)].view.numel() / nr) * sizeof(float);
-                                const size_t off = size_t(r0) * row_bytes;
-                                if (o.data_size > off) {
-                                    p = static_cast<char*>(o.data) + off;
-                                    // the last slice also owns (zero-fills) whatever the caller's buffer has beyond the result
-                                    nb = k == S - 1 ? o.data_size - off : std::min(o.data_size - off, size_t(nr) * row_bytes);
-                                }
-                            }
-                            out_ptr.push_back(p);
-                            out_bytes.push_back(nb);
-                        }
-                        D.InferHost(pi, in_ptr, in_bytes, out_ptr, out_bytes, r.in_u8);
-                    } catch (const std::exception& e) {
-                        errs[size_t(k)] = e.what();
+            bool sharded = false;
+            if (same_rows && num_shards > 1 && rows >= num_shards) {
+                // per-row sizes need the output row size: take it from the primary's plan for one row per shard ... the plan for the
+                // slice is only known inside the slice, so describe outputs by the model's declared dims instead
+                for (size_t i = 0; i < nin; ++i) {
+                    const size_t rb = row_elems(r.shapes[i]) * (r.in_u8[i] ? 1 : sizeof(float));
+                    segs.first[i].push_back({r.in_ptr[i], r.in_ptr[i] ? r.in_bytes[i] : 0, size_t(rows) * rb, 0, r.in_u8[i] != 0});
+                }
+                for (int j = 0; j < r.num_outputs && size_t(j) < nout; ++j) {
+                    const TensorData& o = r.outputs[j];
+                    if (o.data_type != DATATYPE_FLOAT32 || !o.data || o.data_size == 0) continue;
+                    size_t re = 1;
+                    bool known = !info.outputs[size_t(j)].dims.empty();
+                    for (size_t k = 1; k < info.outputs[size_t(j)].dims.size(); ++k) {
+                        if (info.outputs[size_t(j)].dims[k] <= 0) known = false;
+                        else re *= size_t(info.outputs[size_t(j)].dims[k]);
                     }
-                };
-                std::vector<std::thread> workers;
-                for (int k = 1; k < S; ++k) workers.emplace_back(run_slice, k);
-                run_slice(0);
-                for (auto& w : workers) w.join();
-                for (auto& e : errs) if (!e.empty()) { fail_all("ONNX inference error: " + e); return; }
-                write_out_dims(r.outputs, r.num_outputs, pis[0]->plan.outputs, rows);
-                shard_calls.fetch_add(1);
+                    if (!known) { same_rows = false; break; }
+                    segs.second[size_t(j)].push_back({o.data, o.data_size, size_t(rows) * re * sizeof(float), 0});
+                }
+            }
+            if (same_rows && num_shards > 1 && rows >= num_shards) {
+                const ie::PlanInstance* pi = RunOnLanes(r.shapes, rows, true, segs, &sharded);
+                write_out_dims(r.outputs, r.num_outputs, pi->plan.outputs, rows);
+                if (sharded) shard_calls.fetch_add(1);
                 r.ok = true;
                 return;
             }
-        }
-        if (batch.size() == 1 && !(batchable && max_batch > 1 && batch[0]->rows > 0)) {
-            Pending& r = *batch[0];
-            ie::PlanInstance& pi = dev->Prepare(r.shapes);
-            std::vector<void*> out_ptr;
-            std::vector<size_t> out_bytes;
-            for (int i = 0; i < r.num_outputs; ++i) {
-                const bool copy = r.outputs[i].data_type == DATATYPE_FLOAT32 && r.outputs[i].data && r.outputs[i].data_size > 0;
-                out_ptr.push_back(copy ? r.outputs[i].data : nullptr);
-                out_bytes.push_back(copy ? r.outputs[i].data_size : 0);
+            // ---- one request on one lane ----
+            const int k = pool.AcquireAny();
+            if (k < 0) { fail_all("Model not loaded"); return; }
+            try {
+                ie::DeviceModel& D = *lanes[size_t(k)];
+                ie::PlanInstance& pi = D.Prepare(r.shapes, false);
+                std::vector<void*> out_ptr;
+                std::vector<size_t> out_bytes;
+                for (int i = 0; i < r.num_outputs; ++i) {
+                    const bool copy = r.outputs[i].data_type == DATATYPE_FLOAT32 && r.outputs[i].data && r.outputs[i].data_size > 0;
+                    out_ptr.push_back(copy ? r.outputs[i].data : nullptr);
+                    out_bytes.push_back(copy ? r.outputs[i].data_size : 0);
+                }
+                D.InferHost(pi, r.in_ptr, r.in_bytes, out_ptr, out_bytes, r.in_u8);
+                Account(D, pi);
+                write_out_dims(r.outputs, r.num_outputs, pi.plan.outputs, 0);
+                pool.Release(k, 1);
+            } catch (...) {
+                pool.Release(k, 1);
+                throw;
             }
-            dev->InferHost(pi, r.in_ptr, r.in_bytes, out_ptr, out_bytes, r.in_u8);
-            write_out_dims(r.outputs, r.num_outputs, pi.plan.outputs, 0);
             r.ok = true;
             return;
         }
         // ---- coalesced batch: rows of all callers back to back, padded up to a power-of-two bucket so only a handful of
-        //      plans / hipGraphs ever exist ----
+        //      plans / hipGraphs ever exist; with shard replicas the bucket is cut over them like a single large request ----
         int64_t total = 0;
         for (auto* r : batch) total += r->rows;
         int64_t bucket = 1;
@@ -664,28 +960,47 @@ void ModelObj::Execute(std::vector<Pending*>& batch) {
         if (bucket > max_batch && total <= max_batch) bucket = max_batch;
         std::vector<std::vector<int64_t>> shapes = batch[0]->shapes;
         for (auto& sh : shapes) sh[0] = bucket;
-        ie::PlanInstance& pi = dev->Prepare(shapes);
-        std::vector<std::vector<ie::DeviceModel::InSeg>> in(pi.plan.inputs.size());
-        std::vector<std::vector<ie::DeviceModel::OutSeg>> out(pi.plan.outputs.size());
+        std::vector<size_t> out_row_bytes(nout, 0);
+        bool out_known = true;
+        for (size_t j = 0; j < nout; ++j) {
+            size_t re = 1;
+            if (info.outputs[j].dims.empty()) out_known = false;
+            for (size_t k = 1; k < info.outputs[j].dims.size(); ++k) {
+                if (info.outputs[j].dims[k] <= 0) out_known = false;
+                else re *= size_t(info.outputs[j].dims[k]);
+            }
+            out_row_bytes[j] = re * sizeof(float);
+        }
+        if (!out_known) {      // output row size only known from a plan: take it from a one-lane plan of the bucket
+            const int k = pool.AcquireAny();
+            if (k < 0) { fail_all("Model not loaded"); return; }
+            try {
+                ie::PlanInstance& pi = lanes[size_t(k)]->Prepare(shapes, false);
+                for (size_t j = 0; j < nout && j < pi.plan.outputs.size(); ++j) out_row_bytes[j] = size_t(pi.plan.outputs[j].view.numel() / bucket) * sizeof(float);
+                pool.Release(k, 1);
+            } catch (...) { pool.Release(k, 1); throw; }
+        }
         int64_t row0 = 0;
         for (auto* r : batch) {
-            for (size_t k = 0; k < pi.plan.inputs.size(); ++k) {
-                const size_t row_bytes = size_t(pi.plan.inputs[k].view.numel() / bucket) * sizeof(float);
-                in[k].push_back({r->in_ptr[k], r->in_bytes[k], size_t(r->rows) * row_bytes, size_t(row0) * row_bytes});
+            for (size_t k = 0; k < nin; ++k) {
+                const size_t rb = row_elems(shapes[k]) * sizeof(float);
+                segs.first[k].push_back({r->in_ptr[k], r->in_bytes[k], size_t(r->rows) * rb, size_t(row0) * rb});
             }
-            for (int j = 0; j < r->num_outputs && size_t(j) < pi.plan.outputs.size(); ++j) {
+            for (int j = 0; j < r->num_outputs && size_t(j) < nout; ++j) {
                 const TensorData& o = r->outputs[j];
                 if (o.data_type != DATATYPE_FLOAT32 || !o.data || o.data_size == 0) continue;
-                const size_t row_bytes = size_t(pi.plan.outputs[size_t(j)].view.numel() / bucket) * sizeof(float);
-                out[size_t(j)].push_back({o.data, o.data_size, size_t(r->rows) * row_bytes, size_t(row0) * row_bytes});
+                segs.second[size_t(j)].push_back({o.data, o.data_size, size_t(r->rows) * out_row_bytes[size_t(j)], size_t(row0) * out_row_bytes[size_t(j)]});
             }
             row0 += r->rows;
         }
-        dev->InferHostSegments(pi, in, out);
+        // rows of the bucket beyond `total` stay whatever the input buffer held: they are padding whose results nobody reads
+        bool sharded = false;
+        const ie::PlanInstance* pi = RunOnLanes(shapes, bucket, out_known, segs, &sharded);
         device_batches.fetch_add(1);
         coalesced_requests.fetch_add(int64_t(batch.size()));
+        if (sharded) shard_calls.fetch_add(1);
         for (auto* r : batch) {
-            write_out_dims(r->outputs, r->num_outputs, pi.plan.outputs, r->rows);
+            write_out_dims(r->outputs, r->num_outputs, pi->plan.outputs, r->rows);
             r->ok = true;
         }
     } catch (const std::exception& e) {
@@ -728,18 +1043,90 @@ void ModelObj::RunBatched(Pending& req) {
 
 }  // namespace
 
+
+namespace {
+// Runtime facts of a loaded model.  json == false: one line of key=value pairs for ModelMetadata.description; json == true: the
+// document EngineGetRuntimeInfo returns.  The caller holds M.life (shared).
+std::string describe_runtime(ModelObj& M, bool json, bool checksums = false) {
+    double ms, fl, by;
+    int64_t fw, im;
+    { std::lock_guard<std::mutex> g(M.acct_mu); ms = M.acct_ms; fl = M.acct_flops; by = M.acct_bytes; fw = M.acct_forwards; im = M.acct_images; }
+    const bool up = M.loaded.load() && !M.lanes.empty();
+    const ie::Precision prec = up ? M.lanes[0]->precision() : ie::Precision::F32;
+    const char* pname = prec == ie::Precision::F16 ? "fp16" : "fp32";
+    const double mfma_peak = prec == ie::Precision::F16 ? 2500.0 : 157.3;     // TFLOP/s dense, gfx950
+    const double tflops = ms > 0 ? fl / (ms * 1e-3) / 1e12 : 0, gbs = ms > 0 ? by / (ms * 1e-3) / 1e9 : 0;
+    int max_in_flight;
+    { std::lock_guard<std::mutex> g(M.pool.mu); max_in_flight = M.pool.max_in_flight; }
+    std::ostringstream o;
+    o.precision(6);
+    if (!json) {
+        o << "mi355x-engine precision=" << pname << " lanes=" << M.lanes.size() << " shards=" << (up ? M.num_shards : 0) << " forwards=" << fw
+          << " images=" << im << " device_ms_avg=" << (fw ? ms / double(fw) : 0.0) << " achieved_tflops=" << tflops << " frac_mfma_peak=" << tflops / mfma_peak
+          << " algorithmic_gbs=" << gbs << " frac_hbm_peak=" << gbs / 8000.0;
+        return o.str();
+    }
+    o << "{\"loaded\":" << (up ? "true" : "false") << ",\"precision\":\"" << pname << "\",\"lanes\":" << M.lanes.size() << ",\"shards\":" << (up ? M.num_shards : 0)
+      << ",\"lane_devices\":[";
+    for (size_t i = 0; i < M.lanes.size(); ++i) o << (i ? "," : "") << M.lanes[i]->device();
+    o << "],\"lane_shares_weights_with\":[";
+    for (size_t i = 0; i < M.lanes.size(); ++i) {
+        size_t first = i;
+        for (size_t k = 0; k < i; ++k) if (M.lanes[k]->shared_weights() == M.lanes[i]->shared_weights()) { first = k; break; }
+        o << (i ? "," : "") << first;
+    }
+    o << "],\"max_in_flight\":" << max_in_flight << ",\"rccl\":{\"used\":" << (M.rccl.used ? "true" : "false") << ",\"ranks\":" << M.rccl.ranks
+      << ",\"weight_owners\":" << M.rccl.owners << ",\"bytes\":" << M.rccl.bytes << ",\"init_ms\":" << M.rccl.init_ms << ",\"broadcast_ms\":" << M.rccl.bcast_ms
+      << "},\"forwards\":" << fw << ",\"images\":" << im << ",\"device_ms_total\":" << ms << ",\"achieved_tflops\":" << tflops
+      << ",\"mfma_peak_tflops\":" << mfma_peak << ",\"algorithmic_gbs\":" << gbs << ",\"hbm_peak_gbs\":8000";
+    if (up) {
+        o << ",\"pipelined_calls\":[";
+        for (size_t i = 0; i < M.lanes.size(); ++i) o << (i ? "," : "") << M.lanes[i]->pipelined_calls();
+        o << "],\"last_chunks\":" << M.lanes[0]->last_chunks() << ",\"last_head_steps\":" << M.lanes[0]->last_head_steps();
+    }
+    if (up && checksums) {
+        // FNV-1a of every lane's packed fp32 blob as it sits in HBM (a replica filled by the RCCL broadcast must equal the primary)
+        o << ",\"weight_checksums\":[";
+        for (size_t i = 0; i < M.lanes.size(); ++i) {
+            std::vector<char> host(M.lanes[i]->weight_bytes());
+            (void)hipSetDevice(M.lanes[i]->device());
+            if (hipMemcpy(host.data(), M.lanes[i]->weights(), host.size(), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); host.clear(); }
+            o << (i ? "," : "") << "\"" << std::hex << fnv1a64(host.data(), host.size()) << std::dec << "\"";
+        }
+        o << "]";
+    }
+    o << "}";
+    return o.str();
+}
+
+// shared hold on the model's lifetime + exclusive use of the primary lane (the ext API works on lane 0)
+struct Lane0 {
+    ModelObj& M;
+    std::shared_lock<std::shared_mutex> lk;
+    bool ok = false;
+    explicit Lane0(ModelObj& m) : M(m), lk(m.life) {
+        if (M.loaded.load() && !M.lanes.empty()) { M.pool.AcquireOne(0); ok = true; }
+    }
+    ~Lane0() { if (ok) M.pool.Release(0, 1); }
+    ie::DeviceModel* dev() const { return ok ? M.lanes[0].get() : nullptr; }
+};
+}  // namespace
+
 extern "C" {
 
 ModelMetadata* ModelGetMetadata(ModelHandle handle) {
     if (!handle) return nullptr;
     try {
         ModelObj& M = *handle->model;
-        std::lock_guard<std::mutex> g(M.mu);
+        std::shared_lock<std::shared_mutex> g(M.life);
         auto* md = static_cast<ModelMetadata*>(std::calloc(1, sizeof(ModelMetadata)));
         md->name = dup_cstr(M.name);
         md->version = dup_cstr(M.version);
         md->model_type = M.type;
-        md->description = dup_cstr("");
+        // The reference leaves `description` empty (inference_bridge.cpp:836-926).  The engine uses the free-form string to surface
+        // what ModelStats' four fixed counters cannot: device time per forward from HIP events, the planner's
+        // algorithmic FLOP/s and bytes/s of what ran against the gfx950 peaks, lanes / shards.  Go reads it through GetMetadata().
+        md->description = dup_cstr(describe_runtime(M, false));
         md->load_time_ns = M.load_time_ns;
         auto fill = [](const std::vector<std::string>& v, const char*** arr, int* n) {
             *n = int(v.size());
@@ -819,6 +1206,34 @@ char* EngineDescribeModel(const char* path, int batch, ErrorMessage* error) {
         json_vi(o, info.inputs);
         o << ",\"outputs\":";
         json_vi(o, info.outputs);
+        if (std::filesystem::is_directory(path, ec)) {
+            // what the engine reads from <dir>/config.json at load (top-level keys only); a malformed file is an error here as at load
+            const ie::EngineConfig c = ie::LoadEngineConfig(path);
+            auto esc = [](const std::string& t) { std::string r; for (char ch : t) { if (ch == '"' || ch == '\\') r += '\\'; if (static_cast<unsigned char>(ch) >= 0x20) r += ch; } return r; };
+            auto io = [&](const std::vector<ie::IoConfig>& v) {
+                o << "[";
+                for (size_t i = 0; i < v.size(); ++i) {
+                    o << (i ? "," : "") << "{\"name\":\"" << esc(v[i].name) << "\",\"data_type\":\"" << esc(v[i].data_type) << "\",\"label_filename\":\""
+                      << esc(v[i].label_filename) << "\",\"dims\":[";
+                    for (size_t k = 0; k < v[i].dims.size(); ++k) o << (k ? "," : "") << v[i].dims[k];
+                    o << "],\"shape\":[";
+                    for (size_t k = 0; k < v[i].shape.size(); ++k) o << (k ? "," : "") << v[i].shape[k];
+                    o << "]}";
+                }
+                o << "]";
+            };
+            o << ",\"config\":{\"present\":" << (c.present ? "true" : "false") << ",\"name\":\"" << esc(c.name) << "\",\"version\":\"" << esc(c.version)
+              << "\",\"platform\":\"" << esc(c.platform) << "\",\"precision\":\"" << esc(c.precision) << "\",\"gpus\":" << c.gpus
+              << ",\"uint8_scale\":" << c.uint8_scale << ",\"uint8_bias\":" << c.uint8_bias << ",\"dynamic_batching\":" << (c.dynamic_batching ? "true" : "false")
+              << ",\"max_batch_size\":" << c.max_batch_size << ",\"batch_window_us\":" << c.batch_window_us << ",\"instance_count\":" << c.instance_count
+              << ",\"tune_batches\":[";
+            for (size_t k = 0; k < c.tune_batches.size(); ++k) o << (k ? "," : "") << c.tune_batches[k];
+            o << "],\"inputs\":";
+            io(c.inputs);
+            o << ",\"outputs\":";
+            io(c.outputs);
+            o << "}";
+        }
         if (batch > 0) {
             std::vector<std::vector<int64_t>> shapes;
             for (auto& vi : info.inputs) {
@@ -844,15 +1259,15 @@ bool EnginePrepare(ModelHandle handle, const Shape* input_shapes, int num_inputs
     if (!handle) { set_error(error, "Invalid model handle"); return false; }
     try {
         ModelObj& M = *handle->model;
-        std::lock_guard<std::mutex> g(M.mu);
-        if (!M.loaded.load() || !M.dev) { set_error(error, "Model not loaded"); return false; }
+        Lane0 L0(M);
+        if (!L0.dev()) { set_error(error, "Model not loaded"); return false; }
         if (!input_shapes || num_inputs <= 0) { set_error(error, "Invalid parameters"); return false; }
         std::vector<std::vector<int64_t>> shapes;
         for (int i = 0; i < num_inputs; ++i) {
             if (!input_shapes[i].dims || input_shapes[i].num_dims <= 0) { set_error(error, "Invalid parameters"); return false; }
             shapes.emplace_back(input_shapes[i].dims, input_shapes[i].dims + input_shapes[i].num_dims);
         }
-        ie::PlanInstance& pi = M.dev->Prepare(shapes);
+        ie::PlanInstance& pi = L0.dev()->Prepare(shapes, true);
         for (int i = 0; d_inputs && i < num_inputs && size_t(i) < pi.plan.inputs.size(); ++i)
             d_inputs[i] = pi.buffers[size_t(pi.plan.inputs[size_t(i)].view.buf)];
         for (int i = 0; d_outputs && i < num_outputs && size_t(i) < pi.plan.outputs.size(); ++i)
@@ -866,10 +1281,10 @@ bool EngineRunPrepared(ModelHandle handle, int iters, int sync, ErrorMessage* er
     if (!handle) { set_error(error, "Invalid model handle"); return false; }
     try {
         ModelObj& M = *handle->model;
-        std::lock_guard<std::mutex> g(M.mu);
-        if (!M.loaded.load() || !M.dev || !M.dev->current()) { set_error(error, "Model not prepared"); return false; }
-        for (int i = 0; i < iters; ++i) M.dev->Enqueue(*M.dev->current());
-        if (sync) M.dev->Synchronize();
+        Lane0 L0(M);
+        if (!L0.dev() || !L0.dev()->current()) { set_error(error, "Model not prepared"); return false; }
+        for (int i = 0; i < iters; ++i) L0.dev()->Enqueue(*L0.dev()->current());
+        if (sync) L0.dev()->Synchronize();
         return true;
     } catch (const std::exception& e) { set_error(error, e.what()); return false; }
     catch (...) { set_error(error, "unknown error"); return false; }
@@ -879,9 +1294,9 @@ bool EngineSynchronize(ModelHandle handle, ErrorMessage* error) {
     if (!handle) { set_error(error, "Invalid model handle"); return false; }
     try {
         ModelObj& M = *handle->model;
-        std::lock_guard<std::mutex> g(M.mu);
-        if (!M.dev) { set_error(error, "Model not loaded"); return false; }
-        M.dev->Synchronize();
+        Lane0 L0(M);
+        if (!L0.dev()) { set_error(error, "Model not loaded"); return false; }
+        L0.dev()->Synchronize();
         return true;
     } catch (const std::exception& e) { set_error(error, e.what()); return false; }
     catch (...) { set_error(error, "unknown error"); return false; }
@@ -891,8 +1306,8 @@ void* EngineGetStream(ModelHandle handle) {
     if (!handle) return nullptr;
     try {
         ModelObj& M = *handle->model;
-        std::lock_guard<std::mutex> g(M.mu);
-        return M.dev ? static_cast<void*>(M.dev->stream()) : nullptr;
+        std::shared_lock<std::shared_mutex> g(M.life);
+        return M.lanes.empty() ? nullptr : static_cast<void*>(M.lanes[0]->stream());
     } catch (...) { return nullptr; }
 }
 
@@ -900,9 +1315,9 @@ char* EngineProfile(ModelHandle handle, int iters, ErrorMessage* error) {
     if (!handle) { set_error(error, "Invalid model handle"); return nullptr; }
     try {
         ModelObj& M = *handle->model;
-        std::lock_guard<std::mutex> g(M.mu);
-        if (!M.loaded.load() || !M.dev || !M.dev->current()) { set_error(error, "Model not prepared"); return nullptr; }
-        auto t = M.dev->Profile(*M.dev->current(), iters > 0 ? iters : 1);
+        Lane0 L0(M);
+        if (!L0.dev() || !L0.dev()->current()) { set_error(error, "Model not prepared"); return nullptr; }
+        auto t = L0.dev()->Profile(*L0.dev()->current(), iters > 0 ? iters : 1);
         std::ostringstream o;
         o.precision(9);
         o << "[";
@@ -922,10 +1337,10 @@ bool EngineGetWeightBlob(ModelHandle handle, void** d_ptr, size_t* bytes, ErrorM
     if (!handle || !d_ptr || !bytes) { set_error(error, "Invalid parameters"); return false; }
     try {
         ModelObj& M = *handle->model;
-        std::lock_guard<std::mutex> g(M.mu);
-        if (!M.loaded.load() || !M.dev) { set_error(error, "Model not loaded"); return false; }
-        *d_ptr = M.dev->weights();
-        *bytes = M.dev->weight_bytes();
+        Lane0 L0(M);
+        if (!L0.dev()) { set_error(error, "Model not loaded"); return false; }
+        *d_ptr = L0.dev()->weights();
+        *bytes = L0.dev()->weight_bytes();
         return true;
     } catch (const std::exception& e) { set_error(error, e.what()); return false; }
     catch (...) { set_error(error, "unknown error"); return false; }
@@ -935,10 +1350,10 @@ bool EngineWeightsUpdated(ModelHandle handle, ErrorMessage* error) {
     if (!handle) { set_error(error, "Invalid parameters"); return false; }
     try {
         ModelObj& M = *handle->model;
-        std::lock_guard<std::mutex> g(M.mu);
-        if (!M.loaded.load() || !M.dev) { set_error(error, "Model not loaded"); return false; }
-        M.dev->Synchronize();
-        M.dev->RefreshHalfWeights();
+        Lane0 L0(M);
+        if (!L0.dev()) { set_error(error, "Model not loaded"); return false; }
+        L0.dev()->Synchronize();
+        L0.dev()->WeightsArrived();
         return true;
     } catch (const std::exception& e) { set_error(error, e.what()); return false; }
     catch (...) { set_error(error, "unknown error"); return false; }
@@ -947,18 +1362,18 @@ bool EngineWeightsUpdated(ModelHandle handle, ErrorMessage* error) {
 int EngineGetPrecision(ModelHandle handle) {
     if (!handle) return -1;
     ModelObj& M = *handle->model;
-    std::lock_guard<std::mutex> g(M.mu);
-    if (!M.loaded.load() || !M.dev) return -1;
-    return int(M.dev->precision());
+    std::shared_lock<std::shared_mutex> g(M.life);
+    if (!M.loaded.load() || M.lanes.empty()) return -1;
+    return int(M.lanes[0]->precision());
 }
 
 bool EngineMemcpy(ModelHandle handle, void* dst, const void* src, size_t bytes, int kind, ErrorMessage* error) {
     if (!handle || !dst || !src || kind < 1 || kind > 3) { set_error(error, "Invalid parameters"); return false; }
     try {
         ModelObj& M = *handle->model;
-        std::lock_guard<std::mutex> g(M.mu);
-        if (!M.loaded.load() || !M.dev) { set_error(error, "Model not loaded"); return false; }
-        M.dev->Synchronize();
+        Lane0 L0(M);
+        if (!L0.dev()) { set_error(error, "Model not loaded"); return false; }
+        L0.dev()->Synchronize();
         hipMemcpyKind k = kind == 1 ? hipMemcpyHostToDevice : (kind == 2 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice);
         hipError_t e = hipMemcpy(dst, src, bytes, k);
         if (e != hipSuccess) { set_error(error, std::string("HIP error in hipMemcpy: ") + hipGetErrorString(e)); return false; }
@@ -984,10 +1399,28 @@ bool EngineGetBatcherStats(ModelHandle handle, int64_t* device_batches, int64_t*
 bool EngineGetShardStats(ModelHandle handle, int* num_shards, int64_t* sharded_calls) {
     if (!handle) return false;
     ModelObj& M = *handle->model;
-    std::lock_guard<std::mutex> g(M.mu);
-    if (num_shards) *num_shards = M.dev ? int(M.replicas.size()) + 1 : 0;
+    std::shared_lock<std::shared_mutex> g(M.life);
+    if (num_shards) *num_shards = M.lanes.empty() ? 0 : M.num_shards;
     if (sharded_calls) *sharded_calls = M.shard_calls.load();
     return true;
+}
+
+char* EngineGetRuntimeInfo(ModelHandle handle, int with_checksums, ErrorMessage* error) {
+    if (!handle) { set_error(error, "Invalid model handle"); return nullptr; }
+    try {
+        ModelObj& M = *handle->model;
+        std::shared_lock<std::shared_mutex> g(M.life);
+        if (with_checksums && M.loaded.load() && !M.lanes.empty()) {
+            // reading the blobs must not race a forward: hold every lane
+            M.pool.AcquireRange(int(M.lanes.size()));
+            std::string r;
+            try { r = describe_runtime(M, true, true); } catch (...) { M.pool.Release(0, int(M.lanes.size())); throw; }
+            M.pool.Release(0, int(M.lanes.size()));
+            return dup_cstr(r);
+        }
+        return dup_cstr(describe_runtime(M, true, false));
+    } catch (const std::exception& e) { set_error(error, e.what()); return nullptr; }
+    catch (...) { set_error(error, "unknown error"); return nullptr; }
 }
 
 bool EngineVectorAdd(const float* a, const float* b, float* result, size_t n, ErrorMessage* error) {

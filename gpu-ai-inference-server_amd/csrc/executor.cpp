@@ -3,8 +3,11 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
+#include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <unistd.h>
 #include <sstream>
 #include <stdexcept>
 
@@ -18,74 +21,34 @@ void check(hipError_t e, const char* what) {
     if (e != hipSuccess) throw std::runtime_error(std::string("HIP error in ") + what + ": " + hipGetErrorString(e));
 }
 
+// Kernel operand for a planned view.  A chunk instance of the pipelined host path (PlanInstance::batch_off > 0) addresses its
+// image range inside the parent's buffers: same layout, pointer advanced by batch_off images.
 TensorArg make_arg(const PlanInstance& pi, const View& v) {
     TensorArg t;
-    float* base = pi.buffers.at(size_t(v.buf));
+    char* base = reinterpret_cast<char*>(pi.buffers.at(size_t(v.buf)));
     t.n = int(v.n); t.h = int(v.h); t.w = int(v.w); t.c = int(v.c);
     t.f16 = v.f16 ? 1 : 0;
+    const int64_t esize = v.f16 ? 2 : 4;
     if (v.nchw) {
-        t.p = base;
         t.sw = 1; t.sh = v.w; t.sc = v.h * v.w; t.sn = v.c * v.h * v.w;
+        t.p = reinterpret_cast<float*>(base + pi.batch_off * t.sn * esize);
     } else {
-        t.p = v.f16 ? reinterpret_cast<float*>(reinterpret_cast<char*>(base) + v.c_off * 2) : base + v.c_off;
         t.sc = 1; t.sw = v.pitch; t.sh = v.w * v.pitch; t.sn = v.h * v.w * v.pitch;
+        t.p = reinterpret_cast<float*>(base + (v.c_off + pi.batch_off * t.sn) * esize);
     }
     return t;
 }
 
-constexpr size_t kChunk = size_t(4) << 20;   // pinned staging chunk
+constexpr size_t kPinnedBytes = size_t(4) << 20;              // pinned staging for results (logits are KBs; larger outputs go direct)
 constexpr int64_t kTuneWorkspaceFloats = int64_t(16) << 20;   // 64 MiB of split-K slabs available to the autotuner
 constexpr int kNumCounters = 1 << 16;
-constexpr int kSlots = 4;
+constexpr int kMaxChunks = 8;
+constexpr const char* kTuneFileTag = "# ie-tune-v2";
 
 std::once_flag g_kernels_once;
 hipError_t g_kernels_err = hipSuccess;
 
 }  // namespace
-
-CopyPool::CopyPool(int helpers) {
-    for (int i = 0; i < helpers; ++i) threads_.emplace_back([this, i] { Worker(i); });
-}
-CopyPool::~CopyPool() {
-    { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
-    cv_.notify_all();
-    for (auto& t : threads_) t.join();
-}
-void CopyPool::Worker(int idx) {
-    uint64_t seen = 0;
-    for (;;) {
-        char* d; const char* s; size_t n; size_t parts;
-        {
-            std::unique_lock<std::mutex> lk(mu_);
-            cv_.wait(lk, [&] { return stop_ || generation_ != seen; });
-            if (stop_) return;
-            seen = generation_;
-            d = dst_; s = src_; n = n_; parts = threads_.size() + 1;
-        }
-        const size_t per = (n / parts + 63) & ~size_t(63);
-        const size_t b = std::min(n, per * size_t(idx + 1)), e = std::min(n, per * size_t(idx + 2));
-        if (e > b) std::memcpy(d + b, s + b, e - b);
-        {
-            std::lock_guard<std::mutex> g(mu_);
-            if (--pending_ == 0) done_cv_.notify_one();
-        }
-    }
-}
-void CopyPool::Copy(void* dst, const void* src, size_t n) {
-    if (threads_.empty() || n < (size_t(1) << 20)) { std::memcpy(dst, src, n); return; }
-    const size_t parts = threads_.size() + 1;
-    {
-        std::lock_guard<std::mutex> g(mu_);
-        dst_ = static_cast<char*>(dst); src_ = static_cast<const char*>(src); n_ = n;
-        pending_ = int(threads_.size());
-        ++generation_;
-    }
-    cv_.notify_all();
-    const size_t per = (n / parts + 63) & ~size_t(63);
-    std::memcpy(dst, src, std::min(n, per));      // the caller copies slice 0
-    std::unique_lock<std::mutex> lk(mu_);
-    done_cv_.wait(lk, [&] { return pending_ == 0; });
-}
 
 int HipDeviceCount() {
     int n = 0;
@@ -112,8 +75,52 @@ bool HipMemoryInfo(int device_id, size_t* total, size_t* free_b) {
     return ok;
 }
 
-DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id, Precision precision)
-    : model_(std::move(model)), device_(device_id), precision_(precision) {
+DeviceWeights::~DeviceWeights() {
+    (void)hipSetDevice(device);
+    if (d_weights) (void)hipFree(d_weights);
+    if (d_weights16) (void)hipFree(d_weights16);
+    if (d_weights_frag) (void)hipFree(d_weights_frag);
+    if (d_weights8) (void)hipFree(d_weights8);
+}
+
+namespace {
+
+std::string tune_file_header() {
+    std::ostringstream o;
+    o << kTuneFileTag << ' ' << kNumIgemmTiles << ' ' << kNumConvRasterTiles << ' ' << kNumConvWs32Tiles << ' ' << kNumConvWs3Tiles << ' '
+      << kNumConvDirectTiles;
+    return o.str();
+}
+
+// "<signature ints> : <encoded tile> <splitk>" per line behind a header naming the tile tables the numbers index into; a file
+// written by an engine with other tables is ignored as a whole.
+void load_tune_file(const std::string& path, std::map<std::vector<int64_t>, std::pair<int, int>>& cache) {
+    std::ifstream f(path);
+    std::string line;
+    if (!f || !std::getline(f, line) || line != tune_file_header()) return;
+    while (std::getline(f, line)) {
+        std::istringstream is(line);
+        std::vector<int64_t> key;
+        std::string tok;
+        bool ok = true;
+        while (is >> tok && tok != ":") {
+            char* endp = nullptr;
+            const long long v = std::strtoll(tok.c_str(), &endp, 10);
+            if (!endp || *endp) { ok = false; break; }
+            key.push_back(v);
+        }
+        int t = -1, sp = 0;
+        if (ok && (is >> t >> sp) && ((t >= 0 && t < kNumIgemmTiles) || (t >= 100 && t < 100 + kNumConvRasterTiles) || (t >= 200 && t < 200 + kNumConvWs32Tiles) ||
+                                       (t >= 300 && t < 300 + kNumConvWs3Tiles) || (t >= 400 && t < 400 + kNumConvDirectTiles)) &&
+            sp >= 1 && sp <= 64 && key.size() >= 17)
+            cache[key] = {t, sp};
+    }
+}
+
+}  // namespace
+
+DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id, const DeviceModelOptions& opt)
+    : model_(std::move(model)), device_(device_id), precision_(opt.precision) {
     int n = HipDeviceCount();
     if (n <= 0) throw std::runtime_error("No HIP device available: the MI355X engine has no CPU fallback");
     if (device_id < 0 || device_id >= n) throw std::runtime_error("Invalid device id " + std::to_string(device_id));
@@ -128,7 +135,27 @@ DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id, 
         if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsDirect();
     });
     check(g_kernels_err, "InitKernels");
+    if (opt.share) {
+        if (opt.share->device != device_) throw std::runtime_error("internal error: shared weights live on another device");
+        w_ = opt.share;
+    } else {
+        w_ = std::make_shared<DeviceWeights>();
+        w_->device = device_;
+        w_->uploaded = false;
+        owns_weights_ = true;
+        // Persistent kernel-choice cache: IE_TUNE_CACHE=<file> (""/"0" = none), else the path the bridge derived from the model directory.
+        std::string path = opt.tune_cache_path;
+        if (const char* tc = std::getenv("IE_TUNE_CACHE")) path = (tc[0] == 0 || (tc[0] == '0' && tc[1] == 0)) ? std::string() : std::string(tc);
+        w_->tune_cache_path = path;
+        if (!path.empty()) load_tune_file(path, w_->tune_cache);
+    }
+    upload_weights_ = opt.upload_weights;
     check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
+    check(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking), "hipStreamCreate");
+    h2d_events_.resize(kMaxChunks, nullptr);
+    for (auto& e : h2d_events_) check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+    check(hipEventCreate(&t0_event_), "hipEventCreate");
+    check(hipEventCreate(&t1_event_), "hipEventCreate");
     const char* ng = std::getenv("IE_DISABLE_GRAPH");
     use_graph_ = !(ng && ng[0] == '1');
     const char* at = std::getenv("IE_AUTOTUNE");
@@ -137,95 +164,81 @@ DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id, 
     const char* tp = std::getenv("IE_SPLITK_IN_LAUNCH");
     two_pass_splitk_ = !(tp && tp[0] == '1');
     autotune_ = !(at && at[0] == '0') && !std::getenv("IE_FORCE_TILE") && !std::getenv("IE_FORCE_SPLITK") && !std::getenv("IE_FORCE_ALGO");
-    // Optional persistent tuning cache (IE_TUNE_CACHE=<file>): "<17 signature ints> : <tile> <splitk>" per line.
-    if (const char* tc = std::getenv("IE_TUNE_CACHE")) {
-        std::ifstream f(tc);
-        std::string line;
-        while (std::getline(f, line)) {
-            std::istringstream is(line);
-            std::vector<int64_t> key;
-            std::string tok;
-            while (is >> tok && tok != ":") key.push_back(std::stoll(tok));
-            int t = -1, sp = 0;
-            if ((is >> t >> sp) && ((t >= 0 && t < kNumIgemmTiles) || (t >= 100 && t < 100 + kNumConvRasterTiles) || (t >= 200 && t < 200 + kNumConvWs32Tiles) ||
-                                     (t >= 300 && t < 300 + kNumConvWs3Tiles) || (t >= 400 && t < 400 + kNumConvDirectTiles)) &&
-                sp >= 1 && sp <= 64)
-                tune_cache_[key] = {t, sp};
-        }
-    }
-    if (const char* ns = std::getenv("IE_STREAMS")) sub_streams_ = std::max(1, std::min(8, std::atoi(ns)));
+    if (const char* od = std::getenv("IE_TUNE_ON_DEMAND")) tune_on_demand_ = od[0] == '1';
+    if (const char* pc = std::getenv("IE_PIPELINE_CHUNKS")) pipeline_chunks_ = std::max(0, std::min(kMaxChunks, std::atoi(pc)));
+    if (const char* ph = std::getenv("IE_PIPELINE_HEAD")) pipeline_head_ = std::max(0, std::atoi(ph));
     if (const char* mp = std::getenv("IE_MAX_PLANS")) max_plans_ = size_t(std::max(1, std::atoi(mp)));
-    for (int i = 1; i < sub_streams_; ++i) {
-        hipStream_t st = nullptr;
-        check(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
-        side_streams_.push_back(st);
-    }
-    {
-        int helpers = 3;
-        if (const char* h = std::getenv("IE_COPY_THREADS")) helpers = std::max(0, std::min(15, std::atoi(h) - 1));
-        copy_pool_ = std::make_unique<CopyPool>(helpers);
-    }
-    pinned_bytes_ = kChunk * kSlots;
+    pinned_bytes_ = kPinnedBytes;
     check(hipHostMalloc(&pinned_, pinned_bytes_, hipHostMallocDefault), "hipHostMalloc");
 }
 
 DeviceModel::~DeviceModel() {
     (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize(stream_);
+    if (copy_stream_) (void)hipStreamSynchronize(copy_stream_);
     for (auto& kv : plans_) FreeInstance(*kv.second);
-    for (auto st : side_streams_) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
-    if (d_weights_) (void)hipFree(d_weights_);
-    if (d_weights16_) (void)hipFree(d_weights16_);
-    if (d_weights_frag_) (void)hipFree(d_weights_frag_);
+    for (auto e : h2d_events_) if (e) (void)hipEventDestroy(e);
+    if (t0_event_) (void)hipEventDestroy(t0_event_);
+    if (t1_event_) (void)hipEventDestroy(t1_event_);
     if (pinned_) (void)hipHostFree(pinned_);
+    if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
 void DeviceModel::FreeInstance(PlanInstance& pi) {
-    for (auto& sub : pi.subs) FreeInstance(*sub);
+    for (auto& ch : pi.chunks) FreeInstance(*ch);
+    pi.chunks.clear();
     if (pi.graph_exec) (void)hipGraphExecDestroy(pi.graph_exec);
+    if (pi.tail_exec) (void)hipGraphExecDestroy(pi.tail_exec);
+    pi.graph_exec = nullptr;
+    pi.tail_exec = nullptr;
     for (size_t i = 0; i < pi.buffers.size(); ++i)
         if (pi.buffers[i] && pi.owned[i]) (void)hipFree(pi.buffers[i]);
-    if (pi.workspace) (void)hipFree(pi.workspace);
-    if (pi.counters) (void)hipFree(pi.counters);
+    pi.buffers.clear();
+    if (pi.workspace && pi.owns_workspace) (void)hipFree(pi.workspace);
+    if (pi.counters && pi.owns_workspace) (void)hipFree(pi.counters);
+    pi.workspace = nullptr;
+    pi.counters = nullptr;
     for (void* p : pi.u8_stage) if (p) (void)hipFree(p);
-    if (pi.done) (void)hipEventDestroy(pi.done);
-    if (pi.fork) (void)hipEventDestroy(pi.fork);
+    pi.u8_stage.clear();
 }
 
-// Plan + allocate one instance.  io_only: allocate just the graph input/output buffers (parent of sub-batch instances).
-void DeviceModel::BuildInstance(PlanInstance& pi, const std::vector<std::vector<int64_t>>& shapes, bool io_only) {
+// Plan + allocate one instance (and, the first time on this device, put the packed weights into HBM).
+void DeviceModel::BuildInstance(PlanInstance& pi, const std::vector<std::vector<int64_t>>& shapes) {
     pi.plan = BuildPlan(*model_, shapes, precision_);
-    pi.stream = stream_;
-    if (!d_weights_) {
-        weight_floats_ = pi.plan.weights.size();
-        check(hipMalloc(reinterpret_cast<void**>(&d_weights_), std::max<size_t>(weight_floats_, 4) * sizeof(float)), "hipMalloc(weights)");
-        device_bytes_ += weight_floats_ * sizeof(float);
-        check(hipMemcpy(d_weights_, pi.plan.weights.data(), weight_floats_ * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy(weights)");
-        if (precision_ == Precision::F16) {
-            check(hipMalloc(&d_weights16_, std::max<size_t>(weight_floats_, 8) * 2), "hipMalloc(weights16)");
-            device_bytes_ += weight_floats_ * 2;
-        } else if (const char* nf = std::getenv("IE_NO_FRAG_WEIGHTS"); !(nf && std::atoi(nf) != 0)) {
-            for (const Step& st : pi.plan.steps)
-                if (st.kind == StepKind::Conv && st.w_off >= 0 && st.out.c % 16 == 0 && st.in.c % 16 == 0 && st.kh * st.kw <= 49)
-                    frag_regions_.push_back({st.w_off, int(st.out.c), st.kh * st.kw, int(st.in.c)});
-            if (!frag_regions_.empty()) {
-                check(hipMalloc(reinterpret_cast<void**>(&d_weights_frag_), weight_floats_ * sizeof(float)), "hipMalloc(weights_frag)");
-                device_bytes_ += weight_floats_ * sizeof(float);
+    {
+        std::lock_guard<std::mutex> g(w_->tune_mu);     // lanes of one device may be built concurrently
+        if (!w_->d_weights) {
+            w_->weight_floats = pi.plan.weights.size();
+            check(hipMalloc(reinterpret_cast<void**>(&w_->d_weights), std::max<size_t>(w_->weight_floats, 4) * sizeof(float)), "hipMalloc(weights)");
+            w_->device_bytes += w_->weight_floats * sizeof(float);
+            if (upload_weights_) {
+                check(hipMemcpy(w_->d_weights, pi.plan.weights.data(), w_->weight_floats * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy(weights)");
+                w_->uploaded = true;
+            } else {
+                check(hipMemset(w_->d_weights, 0, w_->weight_floats * sizeof(float)), "hipMemset(weights)");
             }
+            if (precision_ == Precision::F16) {
+                check(hipMalloc(&w_->d_weights16, std::max<size_t>(w_->weight_floats, 8) * 2), "hipMalloc(weights16)");
+                w_->device_bytes += w_->weight_floats * 2;
+            } else if (const char* nf = std::getenv("IE_NO_FRAG_WEIGHTS"); !(nf && std::atoi(nf) != 0)) {
+                for (const Step& st : pi.plan.steps)
+                    if (st.kind == StepKind::Conv && st.w_off >= 0 && st.out.c % 16 == 0 && st.in.c % 16 == 0 && st.kh * st.kw <= 49)
+                        w_->frag_regions.push_back({st.w_off, int(st.out.c), st.kh * st.kw, int(st.in.c)});
+                if (!w_->frag_regions.empty()) {
+                    check(hipMalloc(reinterpret_cast<void**>(&w_->d_weights_frag), w_->weight_floats * sizeof(float)), "hipMalloc(weights_frag)");
+                    w_->device_bytes += w_->weight_floats * sizeof(float);
+                }
+            }
+            if (w_->uploaded) WeightsArrived();
+        } else if (pi.plan.weights.size() != w_->weight_floats) {
+            throw std::runtime_error("internal error: weight blob layout depends on the input shape");
         }
-        RefreshHalfWeights();
-    } else if (pi.plan.weights.size() != weight_floats_) {
-        throw std::runtime_error("internal error: weight blob layout depends on the input shape");
     }
     std::vector<float>().swap(pi.plan.weights);   // the host copy of the blob is only needed for the first upload
-    std::vector<char> is_io(pi.plan.buffer_floats.size(), 0);
-    for (auto& d : pi.plan.inputs) is_io[size_t(d.view.buf)] = 1;
-    for (auto& d : pi.plan.outputs) is_io[size_t(d.view.buf)] = 1;
     pi.buffers.assign(pi.plan.buffer_floats.size(), nullptr);
     pi.owned.assign(pi.plan.buffer_floats.size(), 0);
     for (size_t i = 0; i < pi.plan.buffer_floats.size(); ++i) {
-        if (io_only && !is_io[i]) continue;
         float* p = nullptr;
         size_t bytes = size_t(std::max<int64_t>(pi.plan.buffer_floats[i], 8)) * (pi.plan.buffer_f16[i] ? 2 : 4);
         check(hipMalloc(reinterpret_cast<void**>(&p), bytes), "hipMalloc(activations)");
@@ -234,27 +247,50 @@ void DeviceModel::BuildInstance(PlanInstance& pi, const std::vector<std::vector<
         pi.buffers[i] = p;
         pi.owned[i] = 1;
     }
-    if (!io_only) {   // split-K scratch: slabs + per-tile arrival counters (tile-padded slabs need up to 2x the exact S*M*N)
-        pi.workspace_floats = std::max<int64_t>(2 * pi.plan.workspace_floats, kTuneWorkspaceFloats);
-        size_t bytes = size_t(pi.workspace_floats) * sizeof(float);
-        check(hipMalloc(reinterpret_cast<void**>(&pi.workspace), bytes), "hipMalloc(workspace)");
-        device_bytes_ += bytes;
-        if (!two_pass_splitk_) {
-            check(hipMalloc(reinterpret_cast<void**>(&pi.counters), kNumCounters * sizeof(int)), "hipMalloc(counters)");
-            check(hipMemsetAsync(pi.counters, 0, kNumCounters * sizeof(int), stream_), "hipMemset(counters)");
-        }
+    // split-K scratch: slabs + per-tile arrival counters (tile-padded slabs need up to 2x the exact S*M*N)
+    pi.workspace_floats = std::max<int64_t>(2 * pi.plan.workspace_floats, kTuneWorkspaceFloats);
+    size_t bytes = size_t(pi.workspace_floats) * sizeof(float);
+    check(hipMalloc(reinterpret_cast<void**>(&pi.workspace), bytes), "hipMalloc(workspace)");
+    pi.owns_workspace = true;
+    device_bytes_ += bytes;
+    if (!two_pass_splitk_) {
+        check(hipMalloc(reinterpret_cast<void**>(&pi.counters), kNumCounters * sizeof(int)), "hipMalloc(counters)");
+        check(hipMemsetAsync(pi.counters, 0, kNumCounters * sizeof(int), stream_), "hipMemset(counters)");
     }
 }
 
-PlanInstance& DeviceModel::Prepare(const std::vector<std::vector<int64_t>>& shapes) {
+// Capture steps [first, last) of `pi` into an executable graph.
+void DeviceModel::Capture(PlanInstance& pi, size_t first, size_t last, hipGraphExec_t* exec) {
+    hipGraph_t graph = nullptr;
+    check(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+    try {
+        RunSteps(pi, first, last, nullptr);
+    } catch (...) {
+        (void)hipStreamEndCapture(stream_, &graph);
+        if (graph) (void)hipGraphDestroy(graph);
+        throw;
+    }
+    check(hipStreamEndCapture(stream_, &graph), "hipStreamEndCapture");
+    hipError_t e = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    check(e, "hipGraphInstantiate");
+}
+
+PlanInstance& DeviceModel::Prepare(const std::vector<std::vector<int64_t>>& shapes, bool allow_tune) {
     std::vector<int64_t> key;
     for (auto& s : shapes) { key.push_back(int64_t(s.size())); key.insert(key.end(), s.begin(), s.end()); }
     auto touch = [&](const std::vector<int64_t>& k) {
         for (size_t i = 0; i < lru_.size(); ++i) if (lru_[i] == k) { lru_.erase(lru_.begin() + long(i)); break; }
         lru_.push_back(k);
     };
+    check(hipSetDevice(device_), "hipSetDevice");
     auto it = plans_.find(key);
-    if (it != plans_.end()) { touch(key); current_ = it->second.get(); return *current_; }
+    if (it != plans_.end()) {
+        touch(key);
+        current_ = it->second.get();
+        if (allow_tune) EnsurePipeline(*current_, true);
+        return *current_;
+    }
     while (plans_.size() >= max_plans_ && !lru_.empty()) {        // make room: drop the least recently used instance
         check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
         auto old = plans_.find(lru_.front());
@@ -266,83 +302,16 @@ PlanInstance& DeviceModel::Prepare(const std::vector<std::vector<int64_t>>& shap
         lru_.erase(lru_.begin());
     }
 
-    check(hipSetDevice(device_), "hipSetDevice");
-    // Sub-batch split: every graph input shares the leading batch dimension and it divides evenly.
-    int nsub = sub_streams_;
-    int64_t batch = shapes.empty() || shapes[0].empty() ? 0 : shapes[0][0];
-    // Measured on MI355X (DenseNet-121): in fp16 mode the per-launch fixed costs (weight preamble, first loads, store drain) are half
-    // of the forward, and two half-batches on two streams (IE_STREAMS=2) overlap them in back-to-back replays: batch 128 52.6k ->
-    // 56.2k images/s (4 streams: 43k; fp32 batch 32: 10.77k -> 10.57k).
-    // It is NOT the default: a single call's latency gets worse (p50 2.39 -> 2.65 ms per 128-image step, ModelInfer with UINT8
-    // payloads 3.50 -> 3.65 ms) and the ABI path serves one request per model at a time.  IE_STREAMS=2 opts in.
-    for (auto& s : shapes) if (s.empty() || s[0] != batch) nsub = 1;
-    if (batch < 2 * nsub || batch % nsub != 0) nsub = 1;
-
     auto pi = std::make_unique<PlanInstance>();
     try {
-        BuildInstance(*pi, shapes, nsub > 1);
-        if (nsub > 1) {
-            for (auto& d : pi->plan.outputs) if (d.dims.empty() || d.dims[0] != batch) nsub = 1;
-        }
-        if (nsub > 1) {
-            std::vector<std::vector<int64_t>> sub_shapes = shapes;
-            for (auto& s : sub_shapes) s[0] = batch / nsub;
-            check(hipEventCreateWithFlags(&pi->fork, hipEventDisableTiming), "hipEventCreate");
-            for (int k = 0; k < nsub; ++k) {
-                auto sub = std::make_unique<PlanInstance>();
-                try {
-                    BuildInstance(*sub, sub_shapes, false);
-                } catch (const std::exception&) {
-                    // e.g. the model fixes its batch dimension: run the whole batch as one instance
-                    FreeInstance(*sub);
-                    for (auto& s2 : pi->subs) FreeInstance(*s2);
-                    pi->subs.clear();
-                    nsub = 1;
-                    break;
-                }
-                sub->stream = k == 0 ? stream_ : side_streams_[size_t(k - 1)];
-                check(hipEventCreateWithFlags(&sub->done, hipEventDisableTiming), "hipEventCreate");
-                // alias the sub instance's I/O buffers to slices of the parent's full-size buffers
-                auto alias = [&](const std::vector<IoDesc>& sub_io, const std::vector<IoDesc>& full_io) {
-                    for (size_t i = 0; i < sub_io.size(); ++i) {
-                        const size_t sb = size_t(sub_io[i].view.buf), fb = size_t(full_io[i].view.buf);
-                        if (sub->buffers[sb] && sub->owned[sb]) (void)hipFree(sub->buffers[sb]);
-                        sub->buffers[sb] = pi->buffers[fb] + int64_t(k) * sub_io[i].view.numel();
-                        sub->owned[sb] = 0;
-                    }
-                };
-                alias(sub->plan.inputs, pi->plan.inputs);
-                alias(sub->plan.outputs, pi->plan.outputs);
-                pi->subs.push_back(std::move(sub));
-            }
-        }
-        if (nsub == 1 && pi->workspace == nullptr) {
-            // nsub fell back to 1 after an io_only build: rebuild fully
-            FreeInstance(*pi);
-            pi = std::make_unique<PlanInstance>();
-            BuildInstance(*pi, shapes, false);
-        }
+        BuildInstance(*pi, shapes);
         check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
-        if (autotune_) {
-            if (pi->subs.empty()) Autotune(*pi);
-            for (auto& sub : pi->subs) Autotune(*sub);
-        }
+        if (autotune_) Autotune(*pi, pi->plan.steps.size(), allow_tune || tune_on_demand_);
         if (use_graph_) {
-            hipGraph_t graph = nullptr;
-            check(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
-            try {
-                RunSteps(*pi, nullptr, nullptr);
-            } catch (...) {
-                (void)hipStreamEndCapture(stream_, &graph);
-                if (graph) (void)hipGraphDestroy(graph);
-                throw;
-            }
-            check(hipStreamEndCapture(stream_, &graph), "hipStreamEndCapture");
-            hipError_t e = hipGraphInstantiate(&pi->graph_exec, graph, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(graph);
-            check(e, "hipGraphInstantiate");
+            Capture(*pi, 0, pi->plan.steps.size(), &pi->graph_exec);
             pi->graph_ready = true;
         }
+        if (allow_tune) EnsurePipeline(*pi, true);
     } catch (...) {
         FreeInstance(*pi);
         throw;
@@ -354,28 +323,140 @@ PlanInstance& DeviceModel::Prepare(const std::vector<std::vector<int64_t>>& shap
 }
 
 // Rebuilds what is derived from the fp32 weight blob: the half mirror (fp16 mode) or the fragment-major conv weights (fp32 mode).
-void DeviceModel::RefreshHalfWeights() {
-    if (!d_weights16_ && !d_weights_frag_) return;
+void DeviceModel::WeightsArrived() {
+    w_->uploaded = true;
+    if (!w_->d_weights16 && !w_->d_weights_frag) return;
     check(hipSetDevice(device_), "hipSetDevice");
-    if (d_weights16_) check(LaunchConvertF32ToF16(d_weights_, d_weights16_, int64_t(weight_floats_), stream_), "convert_f32_f16");
-    if (d_weights_frag_)
-        for (const FragRegion& fr : frag_regions_)
-            check(LaunchPermuteWeightsFrag(d_weights_ + fr.w_off, d_weights_frag_ + fr.w_off, fr.cout, fr.kk, fr.cin, stream_), "permute_weights_frag");
+    if (w_->d_weights16) check(LaunchConvertF32ToF16(w_->d_weights, w_->d_weights16, int64_t(w_->weight_floats), stream_), "convert_f32_f16");
+    if (w_->d_weights_frag)
+        for (const DeviceWeights::FragRegion& fr : w_->frag_regions)
+            check(LaunchPermuteWeightsFrag(w_->d_weights + fr.w_off, w_->d_weights_frag + fr.w_off, fr.cout, fr.kk, fr.cin, stream_), "permute_weights_frag");
     check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
 }
 
-void DeviceModel::Autotune(PlanInstance& pi) {
+// ---- pipelined host path --------------------------------------------------------------------------------------------------
+// Cut the batch of `pi` into image ranges and decide how many leading steps run per range (PlanInstance::chunks / head_steps).
+// The range plans come from the planner for the range's batch size (so they carry their own kernel choices); they are accepted
+// only when they are the parent's plan with a smaller n: same steps, same views, same weight offsets.
+void DeviceModel::EnsurePipeline(PlanInstance& pi, bool allow_tune) {
+    if (pi.pipeline_tried) return;
+    pi.pipeline_tried = true;
+    if (pipeline_chunks_ < 2 || pi.plan.inputs.empty() || pi.plan.steps.size() < 4) return;
+    const int64_t B = pi.plan.inputs[0].dims.empty() ? 0 : pi.plan.inputs[0].dims[0];
+    for (auto& d : pi.plan.inputs) if (d.dims.empty() || d.dims[0] != B || d.view.n != B) return;
+    for (auto& d : pi.plan.outputs) if (d.dims.empty() || d.dims[0] != B) return;
+    int C = pipeline_chunks_;
+    while (C > 1 && (B % C != 0 || B / C < 4)) C /= 2;
+    if (C < 2) return;
+    const int64_t Bc = B / C;
+    std::vector<std::vector<int64_t>> sub_shapes;
+    for (auto& d : pi.plan.inputs) { sub_shapes.push_back(d.dims); sub_shapes.back()[0] = Bc; }
+    Plan sub;
+    try {
+        sub = BuildPlan(*model_, sub_shapes, precision_);
+    } catch (const std::exception&) {
+        return;          // e.g. the model fixes its batch dimension
+    }
+    const Plan& full = pi.plan;
+    if (sub.steps.size() != full.steps.size() || sub.weights.size() != w_->weight_floats || 2 * sub.workspace_floats > pi.workspace_floats) return;
+    auto same_view = [&](const View& a, const View& b) {
+        return a.buf == b.buf && a.c == b.c && a.h == b.h && a.w == b.w && a.c_off == b.c_off && a.pitch == b.pitch && a.nchw == b.nchw && a.f16 == b.f16 &&
+               a.n * C == b.n;
+    };
+    auto image_stride = [](const View& v) { return v.nchw ? v.c * v.h * v.w : v.h * v.w * v.pitch; };
+    // ---- how many steps per range: enough modelled compute to cover the upload of the remaining ranges ----
+    size_t head = 0;
+    {
+        double in_bytes = 0;
+        for (auto& d : full.inputs) in_bytes += double(d.view.numel()) * 4.0;
+        const double t_h2d = in_bytes * double(C - 1) / double(C) / 40e9;                // pageable H2D: ~40 GB/s measured
+        const double peak = precision_ == Precision::F32 ? 0.45 * 157.3e12 : 0.3 * 2.5e15;
+        double total = 0;
+        std::vector<double> est(full.steps.size());
+        for (size_t i = 0; i < full.steps.size(); ++i) { est[i] = std::max(full.steps[i].flops / peak, full.steps[i].bytes / 2.5e12) + 4e-6; total += est[i]; }
+        const double want = std::min(t_h2d, 0.6 * total);
+        double acc = 0;
+        while (head < full.steps.size() - 1 && acc < want) acc += est[head++];
+        if (pipeline_head_ >= 0) head = std::min<size_t>(size_t(pipeline_head_), full.steps.size() - 1);
+    }
+    // ---- validity: range plan == parent plan with n / C, and no buffer that is read by the tail holds tensors of two different
+    //      image strides during the head (a later range would overwrite an earlier range's live rows) ----
+    auto valid = [&](size_t h) {
+        for (size_t i = 0; i < h; ++i) {
+            const Step &a = sub.steps[i], &b = full.steps[i];
+            if (a.kind != b.kind || !same_view(a.in, b.in) || !same_view(a.out, b.out) || a.has_in2 != b.has_in2 || (a.has_in2 && !same_view(a.in2, b.in2)) ||
+                a.w_off != b.w_off || a.bias_off != b.bias_off || a.pre_scale_off != b.pre_scale_off || a.pre_shift_off != b.pre_shift_off)
+                return false;
+        }
+        std::map<int, int64_t> head_stride;       // buffer -> image stride of the head's tensors in it (-1 = mixed)
+        auto note = [&](const View& v) {
+            auto f = head_stride.find(v.buf);
+            if (f == head_stride.end()) head_stride[v.buf] = image_stride(v);
+            else if (f->second != image_stride(v)) f->second = -1;
+        };
+        for (size_t i = 0; i < h; ++i) { note(full.steps[i].in); note(full.steps[i].out); if (full.steps[i].has_in2) note(full.steps[i].in2); }
+        for (size_t i = h; i < full.steps.size(); ++i)
+            for (const View* v : {&full.steps[i].in, full.steps[i].has_in2 ? &full.steps[i].in2 : nullptr}) {
+                if (!v) continue;
+                auto f = head_stride.find(v->buf);
+                if (f != head_stride.end() && f->second == -1) return false;
+            }
+        return true;
+    };
+    while (head > 0 && !valid(head)) --head;
+    if (head == 0) return;
+    std::vector<float>().swap(sub.weights);
+    for (int c = 0; c < C; ++c) {
+        auto ch = std::make_unique<PlanInstance>();
+        ch->plan = sub;
+        ch->buffers = pi.buffers;
+        ch->owned.assign(pi.buffers.size(), 0);
+        ch->workspace = pi.workspace;
+        ch->workspace_floats = pi.workspace_floats;
+        ch->counters = pi.counters;
+        ch->batch_off = int64_t(c) * Bc;
+        pi.chunks.push_back(std::move(ch));
+    }
+    try {
+        if (autotune_) {
+            Autotune(*pi.chunks[0], head, allow_tune || tune_on_demand_);
+            for (int c = 1; c < C; ++c)
+                for (size_t i = 0; i < head; ++i) {
+                    Step& d = pi.chunks[size_t(c)]->plan.steps[i];
+                    const Step& s0 = pi.chunks[0]->plan.steps[i];
+                    d.algo = s0.algo; d.tile = s0.tile; d.splitk = s0.splitk;
+                }
+        }
+        if (use_graph_) {
+            for (auto& ch : pi.chunks) { Capture(*ch, 0, head, &ch->graph_exec); ch->graph_ready = true; }
+            Capture(pi, head, pi.plan.steps.size(), &pi.tail_exec);
+        }
+    } catch (...) {
+        for (auto& ch : pi.chunks) FreeInstance(*ch);
+        pi.chunks.clear();
+        if (pi.tail_exec) { (void)hipGraphExecDestroy(pi.tail_exec); pi.tail_exec = nullptr; }
+        throw;
+    }
+    pi.head_steps = int(head);
+}
+
+// Kernel choice per conv step of pi.plan.steps[0, nsteps): an exact hit in the device's cache, else (allow_search) the exhaustive
+// timed search, else the cached choice of the same conv at the nearest pixel count (within 2x), else the planner's default.
+void DeviceModel::Autotune(PlanInstance& pi, size_t nsteps, bool allow_search) {
     hipEvent_t e0, e1;
     check(hipEventCreate(&e0), "hipEventCreate");
     check(hipEventCreate(&e1), "hipEventCreate");
     static const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24};
     constexpr size_t kScrubBytes = size_t(64) << 20;       // > 8 x 4 MiB of L2
     void* scrub = nullptr;
-    if (const char* e = std::getenv("IE_TUNE_HOT"); !(e && std::atoi(e) != 0))
+    if (const char* e = std::getenv("IE_TUNE_HOT"); allow_search && !(e && std::atoi(e) != 0))
         if (hipMalloc(&scrub, kScrubBytes) != hipSuccess) { scrub = nullptr; (void)hipGetLastError(); }
+    bool searched = false;
     try {
-        for (Step& s : pi.plan.steps) {
+        for (size_t si = 0; si < nsteps && si < pi.plan.steps.size(); ++si) {
+            Step& s = pi.plan.steps[si];
             if (s.kind != StepKind::Conv || s.algo == ConvAlgo::Naive || s.algo == ConvAlgo::Stem) continue;
+            const Step planned = s;                    // the planner's default, kept when nothing better is known
             // the planner's default may already name a specialised kernel: the search starts from the tiled implicit GEMM either way
             if (s.algo == ConvAlgo::Ws1x1 || s.algo == ConvAlgo::Ws3x3 || s.algo == ConvAlgo::Direct || s.algo == ConvAlgo::Raster3x3) {
                 s.algo = ConvAlgo::IgemmVec;
@@ -390,7 +471,6 @@ void DeviceModel::Autotune(PlanInstance& pi) {
                                         s.in.nchw, int64_t(s.algo), s.pre_scale_off >= 0, s.bias_off >= 0};
             if (s.in.f16 || s.out.f16) { key.push_back(s.in.f16); key.push_back(s.out.f16); }   // fp32 signatures keep 17 entries
             if (s.has_in2) key.push_back(1);              // a fused residual changes which kernels apply (18 / 20 entries)
-            auto hit = tune_cache_.find(key);
             auto apply = [&](int enc_tile, int sp) {     // tile >= 100 encodes the raster kernel, >= 200 the weights-stationary 1x1
                 if (enc_tile >= 400) { s.algo = ConvAlgo::Direct; s.tile = enc_tile - 400; }
                 else if (enc_tile >= 300) { s.algo = ConvAlgo::Ws3x3; s.tile = enc_tile - 300; }
@@ -399,7 +479,40 @@ void DeviceModel::Autotune(PlanInstance& pi) {
                 else s.tile = enc_tile;
                 s.splitk = sp;
             };
-            if (hit != tune_cache_.end()) { apply(hit->second.first, hit->second.second); continue; }
+            {
+                std::pair<int, int> choice{-1, 0};
+                bool exact = false;
+                {
+                    std::lock_guard<std::mutex> g(w_->tune_mu);
+                    auto hit = w_->tune_cache.find(key);
+                    if (hit != w_->tune_cache.end()) { choice = hit->second; exact = true; }
+                    else if (!allow_search) {
+                        // nearest pixel count of the same conv (every other field of the signature equal), at most 2x away
+                        double best_d = 1.0;        // |log2(M' / M)| <= 1
+                        for (const auto& kv : w_->tune_cache) {
+                            if (kv.first.size() != key.size() || !std::equal(kv.first.begin() + 1, kv.first.end(), key.begin() + 1)) continue;
+                            const double d = std::fabs(std::log2(double(kv.first[0]) / double(M)));
+                            if (d <= best_d) { best_d = d; choice = kv.second; }
+                        }
+                    }
+                }
+                if (choice.first >= 0) {
+                    int sp = choice.second;
+                    if (!exact && sp > 1) {     // split-K slabs must fit this instance's workspace at this pixel count
+                        if (choice.first < 100) {
+                            const IgemmTile& T = kIgemmTiles[choice.first];
+                            const int64_t wgs = ((M + T.bm - 1) / T.bm) * ((N + T.bn - 1) / T.bn);
+                            if (KT / sp < 2 || int64_t(sp) * wgs * T.bm * T.bn > pi.workspace_floats || wgs > kNumCounters || wgs * sp > 8192 || wgs >= 1024) sp = 1;
+                        } else if (choice.first < 200) {
+                            if (int64_t(sp) * (M + 256) * (N + 64) * 2 > pi.workspace_floats || (s.in.n * (s.in.h + 1) * (s.in.w + 1)) / 64 * sp > 16384) sp = 1;
+                        } else sp = 1;
+                    }
+                    apply(choice.first, sp);
+                    continue;
+                }
+                if (!allow_search) { s = planned; continue; }
+            }
+            searched = true;
             float best = 1e30f;
             int best_tile = s.tile, best_split = s.splitk;
             auto time_trial = [&](const Step& trial) {
@@ -437,7 +550,7 @@ void DeviceModel::Autotune(PlanInstance& pi) {
                 ConvArgs probe;
                 probe.in = make_arg(pi, s.in);
                 probe.out = make_arg(pi, s.out);
-                probe.w = d_weights_ + s.w_off;
+                probe.w = w_->d_weights + s.w_off;
                 probe.kh = 3; probe.kw = 3; probe.pt = 1; probe.pl = 1;
                 const int64_t chunks = (s.in.c + kIgemmBK - 1) / kIgemmBK;
                 const int64_t Mr = s.in.n * (s.in.h + 1) * (s.in.w + 1);
@@ -518,7 +631,9 @@ void DeviceModel::Autotune(PlanInstance& pi) {
                 }
             }
             apply(best_tile, best_split);
-            tune_cache_[key] = {best_tile, best_split};
+            std::lock_guard<std::mutex> g(w_->tune_mu);
+            w_->tune_cache[key] = {best_tile, best_split};
+            w_->tune_dirty = true;
         }
     } catch (...) {
         (void)hipEventDestroy(e0);
@@ -529,31 +644,45 @@ void DeviceModel::Autotune(PlanInstance& pi) {
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (scrub) (void)hipFree(scrub);
-    if (const char* tc = std::getenv("IE_TUNE_CACHE")) {
-        std::ofstream f(tc, std::ios::trunc);
-        for (auto& kv : tune_cache_) {
+    if (searched) SaveTuneCache();
+}
+
+// Whole-file rewrite through a temporary + rename, so a reader (another process loading the same model) never sees a torn file
+// and concurrent writers cannot interleave lines.
+void DeviceModel::SaveTuneCache() {
+    std::lock_guard<std::mutex> g(w_->tune_mu);
+    if (w_->tune_cache_path.empty() || !w_->tune_dirty) return;
+    const std::string tmp = w_->tune_cache_path + ".tmp" + std::to_string(long(getpid())) + "." + std::to_string(device_);
+    {
+        std::ofstream f(tmp, std::ios::trunc);
+        if (!f) return;                                   // read-only model directory: keep the choices in memory only
+        f << tune_file_header() << '\n';
+        for (auto& kv : w_->tune_cache) {
             for (auto v : kv.first) f << v << ' ';
             f << ": " << kv.second.first << ' ' << kv.second.second << '\n';
         }
+        if (!f.good()) { f.close(); std::remove(tmp.c_str()); return; }
     }
+    if (std::rename(tmp.c_str(), w_->tune_cache_path.c_str()) != 0) std::remove(tmp.c_str());
+    else w_->tune_dirty = false;
 }
 
 ConvArgs DeviceModel::MakeConvArgs(const PlanInstance& pi, const Step& s) const {
-    const float* wb = d_weights_;
+    const float* wb = w_->d_weights;
     auto wp = [&](int64_t off) -> const float* { return off >= 0 ? wb + off : nullptr; };
     ConvArgs a;
     a.in = make_arg(pi, s.in);
     a.out = make_arg(pi, s.out);
     if (s.has_in2) a.res = make_arg(pi, s.in2);
     a.w = wp(s.w_off);
-    a.w16 = d_weights16_ && s.w_off >= 0 ? static_cast<const char*>(d_weights16_) + s.w_off * 2 : nullptr;
-    a.wfrag = d_weights_frag_ && s.w_off >= 0 && s.out.c % 16 == 0 && s.in.c % 16 == 0 && s.kh * s.kw <= 49 ? d_weights_frag_ + s.w_off : nullptr;
+    a.w16 = w_->d_weights16 && s.w_off >= 0 ? static_cast<const char*>(w_->d_weights16) + s.w_off * 2 : nullptr;
+    a.wfrag = w_->d_weights_frag && s.w_off >= 0 && s.out.c % 16 == 0 && s.in.c % 16 == 0 && s.kh * s.kw <= 49 ? w_->d_weights_frag + s.w_off : nullptr;
     a.bias = wp(s.bias_off);
     a.pre_scale = wp(s.pre_scale_off);
     a.pre_shift = wp(s.pre_shift_off);
-    if (d_weights16_ && s.pre_scale_off >= 0) {
-        a.pre_scale16 = static_cast<const char*>(d_weights16_) + s.pre_scale_off * 2;
-        a.pre_shift16 = static_cast<const char*>(d_weights16_) + s.pre_shift_off * 2;
+    if (w_->d_weights16 && s.pre_scale_off >= 0) {
+        a.pre_scale16 = static_cast<const char*>(w_->d_weights16) + s.pre_scale_off * 2;
+        a.pre_shift16 = static_cast<const char*>(w_->d_weights16) + s.pre_shift_off * 2;
     }
     a.kh = s.kh; a.kw = s.kw; a.sh = s.sh; a.sw = s.sw; a.pt = s.pt; a.pl = s.pl;
     a.pre_relu = s.pre_relu; a.relu = s.relu;
@@ -566,7 +695,7 @@ ConvArgs DeviceModel::MakeConvArgs(const PlanInstance& pi, const Step& s) const 
 
 void DeviceModel::LaunchStep(const PlanInstance& pi, const Step& s_in, hipStream_t stream_) {
     const Step& s = s_in;
-    const float* wb = d_weights_;
+    const float* wb = w_->d_weights;
     auto wp = [&](int64_t off) -> const float* { return off >= 0 ? wb + off : nullptr; };
     switch (s.kind) {
         case StepKind::Conv: {
@@ -675,41 +804,19 @@ static std::string kernel_label(const Step& s) {
     return "?";
 }
 
-void DeviceModel::RunSteps(PlanInstance& pi, std::vector<StepTiming>* timings, std::vector<hipEvent_t>* events) {
-    (void)timings;
-    if (!pi.subs.empty() && !events) {
-        // fork: side streams wait for everything enqueued on the main stream so far; join: main waits for every sub-batch
-        check(hipEventRecord(pi.fork, stream_), "hipEventRecord");
-        for (auto& sub : pi.subs) {
-            if (sub->stream != stream_) check(hipStreamWaitEvent(sub->stream, pi.fork, 0), "hipStreamWaitEvent");
-            for (const Step& s : sub->plan.steps) LaunchStep(*sub, s, sub->stream);
-            if (sub->stream != stream_) check(hipEventRecord(sub->done, sub->stream), "hipEventRecord");
-        }
-        for (auto& sub : pi.subs)
-            if (sub->stream != stream_) check(hipStreamWaitEvent(stream_, sub->done, 0), "hipStreamWaitEvent");
-        return;
-    }
-    // single instance, or instrumented pass (sub-batches one after the other on the main stream, an event after every launch)
+void DeviceModel::RunSteps(PlanInstance& pi, size_t first, size_t last, std::vector<hipEvent_t>* events) {
     size_t k = 0;
     if (events) check(hipEventRecord((*events)[k++], stream_), "hipEventRecord");
-    if (pi.subs.empty()) {
-        for (const Step& s : pi.plan.steps) {
-            LaunchStep(pi, s, stream_);
-            if (events) check(hipEventRecord((*events)[k++], stream_), "hipEventRecord");
-        }
-    } else {
-        for (auto& sub : pi.subs)
-            for (const Step& s : sub->plan.steps) {
-                LaunchStep(*sub, s, stream_);
-                if (events) check(hipEventRecord((*events)[k++], stream_), "hipEventRecord");
-            }
+    for (size_t i = first; i < last && i < pi.plan.steps.size(); ++i) {
+        LaunchStep(pi, pi.plan.steps[i], stream_);
+        if (events) check(hipEventRecord((*events)[k++], stream_), "hipEventRecord");
     }
 }
 
 void DeviceModel::Enqueue(PlanInstance& pi) {
     check(hipSetDevice(device_), "hipSetDevice");
     if (pi.graph_ready) check(hipGraphLaunch(pi.graph_exec, stream_), "hipGraphLaunch");
-    else RunSteps(pi, nullptr, nullptr);
+    else RunSteps(pi, 0, pi.plan.steps.size(), nullptr);
 }
 
 void DeviceModel::Synchronize() {
@@ -719,24 +826,21 @@ void DeviceModel::Synchronize() {
 
 std::vector<StepTiming> DeviceModel::Profile(PlanInstance& pi, int iters) {
     check(hipSetDevice(device_), "hipSetDevice");
-    std::vector<const Step*> steps;
-    if (pi.subs.empty()) for (const Step& s : pi.plan.steps) steps.push_back(&s);
-    else for (auto& sub : pi.subs) for (const Step& s : sub->plan.steps) steps.push_back(&s);
-    const size_t ns = steps.size();
+    const size_t ns = pi.plan.steps.size();
     std::vector<hipEvent_t> ev(ns + 1);
     for (auto& e : ev) check(hipEventCreate(&e), "hipEventCreate");
     std::vector<StepTiming> out(ns);
     for (size_t i = 0; i < ns; ++i) {
-        out[i].name = steps[i]->name;
-        out[i].kernel = kernel_label(*steps[i]);
-        out[i].flops = steps[i]->flops;
-        out[i].bytes = steps[i]->bytes;
+        out[i].name = pi.plan.steps[i].name;
+        out[i].kernel = kernel_label(pi.plan.steps[i]);
+        out[i].flops = pi.plan.steps[i].flops;
+        out[i].bytes = pi.plan.steps[i].bytes;
     }
     try {
-        RunSteps(pi, nullptr, nullptr);   // warm
+        RunSteps(pi, 0, ns, nullptr);   // warm
         check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
         for (int it = 0; it < iters; ++it) {
-            RunSteps(pi, nullptr, &ev);
+            RunSteps(pi, 0, ns, &ev);
             check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
             for (size_t i = 0; i < ns; ++i) {
                 float ms = 0;
@@ -768,20 +872,27 @@ void DeviceModel::InferHost(PlanInstance& pi, const std::vector<const void*>& in
     InferHostSegments(pi, in, out);
 }
 
+// The ModelInfer data path: caller memory -> HBM, forward, HBM -> caller memory.  This replaces the five host copies each way of
+// the reference (inference_bridge.cpp:738-749, 806-812 and model.cpp:1229-1238, 1290-1311) with ONE DMA per direction straight
+// from / to the caller's buffers (hipMemcpyAsync takes pageable memory at ~40-55 GB/s on this platform, measured by
+// scripts/probes/h2d_probe.cpp; a caller that hands over pinned memory gets a fully asynchronous copy), and overlaps the upload
+// with compute: the batch is cut into image ranges, range c's upload is followed by the head steps of range c on the compute
+// stream while range c+1 uploads on the copy stream; the remaining steps run once on the whole batch.
 void DeviceModel::InferHostSegments(PlanInstance& pi, const std::vector<std::vector<InSeg>>& in, const std::vector<std::vector<OutSeg>>& out) {
     check(hipSetDevice(device_), "hipSetDevice");
-    hipEvent_t slot_ev[kSlots];
-    for (auto& e : slot_ev) check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
-    bool slot_used[kSlots] = {false, false, false, false};
-    int slot = 0;
-    auto fail_cleanup = [&] { for (auto& e : slot_ev) (void)hipEventDestroy(e); };
+    EnsurePipeline(pi, false);
+    const int C = pi.chunks.empty() ? 1 : int(pi.chunks.size());
+    struct Job { int chunk; char* dst; const char* src; size_t copy, zero; };      // copy `copy` bytes src -> dst, then zero `zero` bytes behind them
+    std::vector<Job> jobs;
+    struct U8 { size_t input; };
+    std::vector<char> is_u8(pi.plan.inputs.size(), 0);
     try {
-        // ---- H2D: caller memory -> pinned ring -> device, CPU copy of chunk k+1 overlaps the DMA of chunk k ----
         for (size_t i = 0; i < pi.plan.inputs.size() && i < in.size(); ++i) {
             const View& v = pi.plan.inputs[i].view;
             char* base = reinterpret_cast<char*>(pi.buffers[size_t(v.buf)]);
             const bool u8 = !in[i].empty() && in[i][0].u8;
-            if (u8) {       // bytes go to a device staging buffer; one kernel converts them into the fp32 input buffer afterwards
+            is_u8[i] = u8 ? 1 : 0;
+            if (u8) {       // bytes go to a device staging buffer; a kernel per range converts them into the fp32 input buffer
                 if (pi.u8_stage.size() < pi.plan.inputs.size()) pi.u8_stage.resize(pi.plan.inputs.size(), nullptr);
                 if (!pi.u8_stage[i]) {
                     check(hipMalloc(&pi.u8_stage[i], std::max<size_t>(size_t(v.numel()), 16)), "hipMalloc(u8 staging)");
@@ -789,70 +900,107 @@ void DeviceModel::InferHostSegments(PlanInstance& pi, const std::vector<std::vec
                 }
                 base = static_cast<char*>(pi.u8_stage[i]);
             }
+            const size_t total = size_t(v.numel()) * (u8 ? 1 : sizeof(float));
+            const size_t per_chunk = total / size_t(C);          // C divides the batch, so ranges are whole images
             for (const InSeg& sg : in[i]) {
                 if (sg.u8 != u8) throw std::runtime_error("internal error: mixed UINT8 / FLOAT32 segments for one input");
-                char* dst = base + sg.dev_off;
+                if (sg.dev_off + sg.need > total) throw std::runtime_error("internal error: input segment exceeds the planned tensor");
                 const size_t have = sg.host ? std::min(sg.have, sg.need) : 0;
-                for (size_t off = 0; off < have; off += kChunk) {
-                    const size_t nb = std::min(kChunk, have - off);
-                    if (slot_used[slot]) check(hipEventSynchronize(slot_ev[slot]), "hipEventSynchronize");
-                    char* stage = static_cast<char*>(pinned_) + size_t(slot) * kChunk;
-                    copy_pool_->Copy(stage, static_cast<const char*>(sg.host) + off, nb);
-                    check(hipMemcpyAsync(dst + off, stage, nb, hipMemcpyHostToDevice, stream_), "hipMemcpyAsync(H2D)");
-                    check(hipEventRecord(slot_ev[slot], stream_), "hipEventRecord");
-                    slot_used[slot] = true;
-                    slot = (slot + 1) % kSlots;
+                size_t off = 0;
+                while (off < sg.need) {                          // split at range boundaries
+                    const size_t dev = sg.dev_off + off;
+                    const int c = int(std::min<size_t>(dev / per_chunk, size_t(C - 1)));
+                    const size_t end = std::min(sg.need, (size_t(c) + 1) * per_chunk - sg.dev_off);
+                    const size_t nb = end - off;
+                    const size_t cp = off < have ? std::min(nb, have - off) : 0;
+                    jobs.push_back({c, base + dev, cp ? static_cast<const char*>(sg.host) + off : nullptr, cp, nb - cp});
+                    off = end;
                 }
-                if (have < sg.need) check(hipMemsetAsync(dst + have, 0, sg.need - have, stream_), "hipMemsetAsync");
             }
-            if (u8)
-                check(LaunchConvertU8ToF32(pi.u8_stage[i], pi.buffers[size_t(v.buf)], v.numel(), u8_scale_, u8_bias_, stream_), "convert_u8_f32");
         }
-        Enqueue(pi);
-        // ---- D2H: one transfer per output when it fits the ring, then per-caller scatter on the host ----------
+        // ---- upload + head, range by range ----
+        for (int c = 0; c < C; ++c) {
+            for (const Job& j : jobs) {
+                if (j.chunk != c) continue;
+                if (j.copy) check(hipMemcpyAsync(j.dst, j.src, j.copy, hipMemcpyHostToDevice, copy_stream_), "hipMemcpyAsync(H2D)");
+                if (j.zero) check(hipMemsetAsync(j.dst + j.copy, 0, j.zero, copy_stream_), "hipMemsetAsync");
+            }
+            for (size_t i = 0; i < pi.plan.inputs.size(); ++i) {
+                if (!is_u8[i]) continue;
+                const View& v = pi.plan.inputs[i].view;
+                const int64_t n = v.numel() / C;
+                check(LaunchConvertU8ToF32(static_cast<char*>(pi.u8_stage[i]) + int64_t(c) * n, pi.buffers[size_t(v.buf)] + int64_t(c) * n, n, u8_scale_, u8_bias_,
+                                           copy_stream_), "convert_u8_f32");
+            }
+            check(hipEventRecord(h2d_events_[size_t(c)], copy_stream_), "hipEventRecord");
+            check(hipStreamWaitEvent(stream_, h2d_events_[size_t(c)], 0), "hipStreamWaitEvent");
+            if (c == 0) check(hipEventRecord(t0_event_, stream_), "hipEventRecord");
+            if (C > 1) {
+                PlanInstance& ch = *pi.chunks[size_t(c)];
+                if (ch.graph_ready) check(hipGraphLaunch(ch.graph_exec, stream_), "hipGraphLaunch(head)");
+                else RunSteps(ch, 0, size_t(pi.head_steps), nullptr);
+            }
+        }
+        if (C > 1) {
+            if (pi.tail_exec) check(hipGraphLaunch(pi.tail_exec, stream_), "hipGraphLaunch(tail)");
+            else RunSteps(pi, size_t(pi.head_steps), pi.plan.steps.size(), nullptr);
+            ++pipelined_calls_;
+        } else {
+            Enqueue(pi);
+        }
+        check(hipEventRecord(t1_event_, stream_), "hipEventRecord");
+        last_chunks_ = C;
+        last_head_steps_ = C > 1 ? pi.head_steps : 0;
+        // ---- D2H: results are small (logits): one transfer per output into pinned staging, ONE synchronisation, then the
+        //      per-caller scatter on the host; an output too large for the staging goes straight to the caller's memory ----
+        struct Scatter { size_t j, lo, stage_off; };
+        std::vector<Scatter> staged;
+        size_t stage_used = 0;
         for (size_t j = 0; j < pi.plan.outputs.size() && j < out.size(); ++j) {
             if (out[j].empty()) continue;
             const View& v = pi.plan.outputs[j].view;
             const char* src = reinterpret_cast<const char*>(pi.buffers[size_t(v.buf)]);
+            const size_t total = size_t(v.numel()) * sizeof(float);
             size_t lo = SIZE_MAX, hi = 0;
             for (const OutSeg& sg : out[j]) {
                 const size_t nb = std::min(sg.cap, sg.need);
                 if (!nb) continue;
+                if (sg.dev_off + nb > total) throw std::runtime_error("internal error: output segment exceeds the planned tensor");
                 lo = std::min(lo, sg.dev_off);
                 hi = std::max(hi, sg.dev_off + nb);
             }
-            if (hi > lo && hi - lo <= kChunk * kSlots) {
-                check(hipStreamSynchronize(stream_), "hipStreamSynchronize");     // ring is free again
-                check(hipMemcpyAsync(pinned_, src + lo, hi - lo, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(D2H)");
-                check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
-                for (const OutSeg& sg : out[j]) {
-                    const size_t nb = std::min(sg.cap, sg.need);
-                    if (nb) std::memcpy(sg.host, static_cast<char*>(pinned_) + (sg.dev_off - lo), nb);
-                }
+            if (hi <= lo) continue;
+            if (stage_used + (hi - lo) <= pinned_bytes_) {
+                check(hipMemcpyAsync(static_cast<char*>(pinned_) + stage_used, src + lo, hi - lo, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(D2H)");
+                staged.push_back({j, lo, stage_used});
+                stage_used += (hi - lo + 63) & ~size_t(63);
             } else {
                 for (const OutSeg& sg : out[j]) {
-                    const size_t nbytes = std::min(sg.cap, sg.need);
-                    for (size_t off = 0; off < nbytes; off += kChunk * kSlots) {
-                        const size_t nb = std::min(kChunk * kSlots, nbytes - off);
-                        check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
-                        check(hipMemcpyAsync(pinned_, src + sg.dev_off + off, nb, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(D2H)");
-                        check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
-                        std::memcpy(static_cast<char*>(sg.host) + off, pinned_, nb);
-                    }
+                    const size_t nb = std::min(sg.cap, sg.need);
+                    if (nb) check(hipMemcpyAsync(sg.host, src + sg.dev_off, nb, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(D2H)");
                 }
             }
+        }
+        check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+        {
+            float ms = 0;
+            last_forward_ms_ = hipEventElapsedTime(&ms, t0_event_, t1_event_) == hipSuccess ? double(ms) : 0.0;
+        }
+        for (const Scatter& sc : staged)
+            for (const OutSeg& sg : out[sc.j]) {
+                const size_t nb = std::min(sg.cap, sg.need);
+                if (nb) std::memcpy(sg.host, static_cast<char*>(pinned_) + sc.stage_off + (sg.dev_off - sc.lo), nb);
+            }
+        for (size_t j = 0; j < out.size(); ++j)
             for (const OutSeg& sg : out[j]) {
                 const size_t nb = std::min(sg.cap, sg.need);
                 if (sg.cap > nb) std::memset(static_cast<char*>(sg.host) + nb, 0, sg.cap - nb);
             }
-        }
-        check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
     } catch (...) {
+        (void)hipStreamSynchronize(copy_stream_);
         (void)hipStreamSynchronize(stream_);
-        fail_cleanup();
         throw;
     }
-    fail_cleanup();
 }
 
 }  // namespace ie

@@ -1,17 +1,21 @@
-// Device-side model: weights resident in HBM, planned activation buffers, one hipGraph per input shape.
+// Device-side model: weights resident in HBM, planned activation buffers, hipGraphs per input shape.
 //
 // MI355X-native replacement for the Ort::Session the reference owns per model
 // (inference_engine/src/model.cpp:706-714, created at :847, run at :1264-1270).
+//
+// Ownership: one DeviceWeights per (model, device) holds everything derived from the ONNX initializers (the packed fp32 blob
+// and its half / fragment-major / fp8 mirrors) plus the kernel-choice cache.  One DeviceModel is one EXECUTION LANE on that
+// device: its own streams, events, pinned staging, plan instances and hipGraphs.  Lanes on the same device share a
+// DeviceWeights (config.json "instance_count"), replicas on other devices own theirs and receive the blob by RCCL broadcast
+// (bridge.cpp).  A lane is used by one host thread at a time; the bridge's lane pool guarantees that.
 #pragma once
 #include <hip/hip_runtime.h>
 
 #include <atomic>
-#include <condition_variable>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "kernels.h"
@@ -25,56 +29,66 @@ struct StepTiming {
     double ms = 0, flops = 0, bytes = 0;
 };
 
-struct PlanInstance {
-    Plan plan;
-    std::vector<float*> buffers;       // device activation buffers (plan.buffer_floats); aliased I/O entries are not owned
-    std::vector<char> owned;           // buffers[i] was hipMalloc'ed by this instance
-    // Sub-batch streams: a batch of B images can run as S independent sub-batches of B/S on S streams inside ONE
-    // hipGraph (fork/join).  Layers whose output grid cannot fill 256 CUs (dense blocks 3-4 at batch 32) are latency
-    // bound, so two half-batches in flight together use the idle CUs.  The parent instance then owns only the
-    // full-size input/output buffers; each sub instance owns its activations and aliases slices of the parent's I/O.
-    std::vector<std::unique_ptr<PlanInstance>> subs;
-    hipStream_t stream = nullptr;      // stream this instance's kernels are enqueued on
-    hipEvent_t done = nullptr;         // join event (sub instances on side streams)
-    hipEvent_t fork = nullptr;         // parent only
-    float* workspace = nullptr;        // split-K slabs
-    int64_t workspace_floats = 0;
-    int* counters = nullptr;           // split-K arrival counters (zero between launches)
-    hipGraphExec_t graph_exec = nullptr;
-    bool graph_ready = false;
-    std::vector<void*> u8_stage;       // per graph input: device staging for UINT8 payloads (allocated on first use)
+struct DeviceWeights {
+    int device = 0;
+    float* d_weights = nullptr;        // packed fp32 blob (what the RCCL broadcast moves)
+    void* d_weights16 = nullptr;       // fp16 / fp8 modes: the same blob as halfs, same element offsets
+    float* d_weights_frag = nullptr;   // fp32 mode: conv weights again in MFMA-fragment order at the same offsets
+    void* d_weights8 = nullptr;        // fp8 mode: conv weights as OCP e4m3 bytes at the same element offsets (per-output-channel scaled)
+    struct FragRegion { int64_t w_off; int cout, kk, cin; };
+    std::vector<FragRegion> frag_regions;
+    size_t weight_floats = 0;
+    bool uploaded = false;             // the fp32 blob holds the model's weights (false until the upload or the broadcast happened)
+    std::atomic<size_t> device_bytes{0};
+    // kernel choices found by the search, shared by every lane of the device: conv signature -> (encoded tile, split-K)
+    std::mutex tune_mu;
+    std::map<std::vector<int64_t>, std::pair<int, int>> tune_cache;
+    std::string tune_cache_path;       // "" = not persisted
+    bool tune_dirty = false;
+    ~DeviceWeights();
 };
 
-// A few helper threads that split big host memcpys (caller buffer -> pinned staging).  One thread moves ~10 GB/s, the
-// PCIe Gen5 link ~55 GB/s: without help the CPU copy, not the DMA, bounds ModelInfer's H2D stage.
-class CopyPool {
-public:
-    explicit CopyPool(int helpers);
-    ~CopyPool();
-    void Copy(void* dst, const void* src, size_t n);
-private:
-    void Worker(int idx);
-    std::vector<std::thread> threads_;
-    std::mutex mu_;
-    std::condition_variable cv_, done_cv_;
-    char* dst_ = nullptr;
-    const char* src_ = nullptr;
-    size_t n_ = 0;
-    uint64_t generation_ = 0;
-    int pending_ = 0;
-    bool stop_ = false;
+struct PlanInstance {
+    Plan plan;
+    std::vector<float*> buffers;       // device activation buffers (plan.buffer_floats); aliased entries are not owned
+    std::vector<char> owned;           // buffers[i] was hipMalloc'ed by this instance
+    float* workspace = nullptr;        // split-K slabs
+    bool owns_workspace = false;
+    int64_t workspace_floats = 0;
+    int* counters = nullptr;           // split-K arrival counters (zero between launches)
+    hipGraphExec_t graph_exec = nullptr;   // the whole forward (device-resident replay); for a chunk instance: its head steps
+    bool graph_ready = false;
+    std::vector<void*> u8_stage;       // per graph input: device staging for UINT8 payloads (allocated on first use)
+    // ---- pipelined host path (ModelInfer): the batch is cut into `chunks.size()` image ranges; the first `head_steps` steps run
+    // per range as soon as that range's H2D has landed (every step is batch-parallel, a range is a pointer offset), the rest runs
+    // once on the whole batch.  Chunk instances hold the plan for the range's batch size (own kernel choices) and alias the
+    // parent's buffers.
+    std::vector<std::unique_ptr<PlanInstance>> chunks;
+    int64_t batch_off = 0;             // chunk instance: first image of its range inside the parent's tensors
+    int head_steps = 0;
+    hipGraphExec_t tail_exec = nullptr;
+    bool pipeline_tried = false;
+};
+
+struct DeviceModelOptions {
+    Precision precision = Precision::F32;
+    std::shared_ptr<DeviceWeights> share;   // lane on a device that already holds the weights
+    bool upload_weights = true;             // false: allocate the blob only (an RCCL broadcast fills it, then WeightsArrived())
+    std::string tune_cache_path;            // where the kernel-choice cache is persisted ("" = nowhere)
 };
 
 class DeviceModel {
 public:
     // Parses nothing itself: takes the decoded graph. Throws std::runtime_error (never falls back to a CPU path).
-    DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id, Precision precision = Precision::F32);
+    DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id, const DeviceModelOptions& opt);
     ~DeviceModel();
     DeviceModel(const DeviceModel&) = delete;
     DeviceModel& operator=(const DeviceModel&) = delete;
 
-    // Get (or build: plan + allocate + capture) the instance for these input shapes.
-    PlanInstance& Prepare(const std::vector<std::vector<int64_t>>& shapes);
+    // Get (or build: plan + allocate + capture) the instance for these input shapes.  allow_tune: run the exhaustive kernel
+    // search for conv signatures not in the cache (load time / EnginePrepare); without it (the request path) unseen signatures
+    // take the cached choice of the nearest pixel count or the planner's default -- a request never waits for a search.
+    PlanInstance& Prepare(const std::vector<std::vector<int64_t>>& shapes, bool allow_tune);
     // Enqueue one forward of `pi` on the model stream (graph replay when available).
     void Enqueue(PlanInstance& pi);
     // Eager forward with hipEvents around every launch; per-step times in ms (averaged over iters).
@@ -89,8 +103,8 @@ public:
     void InferHost(PlanInstance& pi, const std::vector<const void*>& inputs, const std::vector<size_t>& in_bytes,
                    const std::vector<void*>& outputs, const std::vector<size_t>& out_bytes, const std::vector<char>& in_u8 = {});
     void SetU8Transform(float scale, float bias) { u8_scale_ = scale; u8_bias_ = bias; }
-    // Gather/scatter form used by the dynamic batcher: several callers' row blocks land at byte offsets of one device batch.
-    // Input segment: `have` valid bytes at `host`, zero-extended to `need` bytes, placed at `dev_off` of input k.
+    // Gather/scatter form used by the dynamic batcher and the sharder: several callers' row blocks land at byte offsets of one
+    // device batch.  Input segment: `have` valid bytes at `host`, zero-extended to `need` bytes, placed at `dev_off` of input k.
     // Output segment: min(cap, need) bytes from `dev_off` of output j copied to `host`, the rest of `cap` zero-filled.
     struct InSeg { const void* host; size_t have, need, dev_off; bool u8 = false; };   // u8: have/need/dev_off count bytes = elements
     struct OutSeg { void* host; size_t cap, need, dev_off; };
@@ -98,54 +112,63 @@ public:
 
     hipStream_t stream() const { return stream_; }
     int device() const { return device_; }
-    float* weights() const { return d_weights_; }
+    float* weights() const { return w_->d_weights; }
+    const std::shared_ptr<DeviceWeights>& shared_weights() const { return w_; }
     Precision precision() const { return precision_; }
-    // fp16 mode keeps a half mirror of the fp32 weight blob; call after the blob was rewritten in place (RCCL broadcast).
-    void RefreshHalfWeights();
-    size_t weight_bytes() const { return weight_floats_ * sizeof(float); }
-    size_t device_bytes() const { return device_bytes_; }
-    std::mutex& mutex() { return mu_; }
+    // The fp32 blob was (re)written in place (RCCL broadcast, EngineWeightsUpdated): rebuild the half / fragment-major mirrors.
+    void WeightsArrived();
+    size_t weight_bytes() const { return w_->weight_floats * sizeof(float); }
+    size_t device_bytes() const { return device_bytes_ + w_->device_bytes.load(); }
     PlanInstance* current() { return current_; }
+    // counters of the pipelined host path (observability / tests)
+    int64_t pipelined_calls() const { return pipelined_calls_; }
+    int last_chunks() const { return last_chunks_; }
+    int last_head_steps() const { return last_head_steps_; }
+    double last_forward_ms() const { return last_forward_ms_; }
 
 private:
-    void RunSteps(PlanInstance& pi, std::vector<StepTiming>* timings, std::vector<hipEvent_t>* events);
-    void BuildInstance(PlanInstance& pi, const std::vector<std::vector<int64_t>>& shapes, bool io_only);
+    void RunSteps(PlanInstance& pi, size_t first, size_t last, std::vector<hipEvent_t>* events);
+    void BuildInstance(PlanInstance& pi, const std::vector<std::vector<int64_t>>& shapes);
     void FreeInstance(PlanInstance& pi);
+    void Capture(PlanInstance& pi, size_t first, size_t last, hipGraphExec_t* exec);
     // Exhaustive (tile, split-K) search per distinct conv shape, timed with HIP events on the model's stream; the
-    // MI355X counterpart of the reference's cudnn_conv_algo_search = Exhaustive (model.cpp:886).
-    void Autotune(PlanInstance& pi);
+    // MI355X counterpart of the reference's cudnn_conv_algo_search = Exhaustive (model.cpp:886).  Only steps [0, nsteps).
+    void Autotune(PlanInstance& pi, size_t nsteps, bool allow_search);
+    void SaveTuneCache();
+    void EnsurePipeline(PlanInstance& pi, bool allow_tune);
     void LaunchStep(const PlanInstance& pi, const Step& s, hipStream_t stream);
     ConvArgs MakeConvArgs(const PlanInstance& pi, const Step& s) const;
 
     std::shared_ptr<const OnnxModel> model_;
     int device_ = 0;
-    hipStream_t stream_ = nullptr;
-    float* d_weights_ = nullptr;
-    void* d_weights16_ = nullptr;      // fp16 mode: the same blob as halfs, same element offsets
-    float* d_weights_frag_ = nullptr;  // fp32 mode: conv weights again in MFMA-fragment order at the same offsets (window kernels)
-    struct FragRegion { int64_t w_off; int cout, kk, cin; };
-    std::vector<FragRegion> frag_regions_;
+    hipStream_t stream_ = nullptr;       // compute
+    hipStream_t copy_stream_ = nullptr;  // H2D of the pipelined host path
+    std::vector<hipEvent_t> h2d_events_;
+    hipEvent_t t0_event_ = nullptr, t1_event_ = nullptr;   // device time of the last host-path forward
+    std::shared_ptr<DeviceWeights> w_;
+    bool owns_weights_ = false;
+    bool upload_weights_ = true;
     Precision precision_ = Precision::F32;
-    size_t weight_floats_ = 0;
     size_t device_bytes_ = 0;
     float u8_scale_ = 1.0f / 255.0f, u8_bias_ = 0.0f;
     bool use_graph_ = true;
     bool autotune_ = true;
-    int sub_streams_ = 1;              // IE_STREAMS: sub-batches run concurrently per forward
-    std::vector<hipStream_t> side_streams_;
+    bool tune_on_demand_ = false;      // IE_TUNE_ON_DEMAND=1: search on the request path too (round-1 behaviour)
+    int pipeline_chunks_ = 4;          // IE_PIPELINE_CHUNKS (0/1 = off)
+    int pipeline_head_ = -1;           // IE_PIPELINE_HEAD: steps run per chunk (-1 = modelled)
     bool two_pass_splitk_ = true;      // IE_SPLITK_IN_LAUNCH=1 selects the in-launch combine instead of the reduce kernel
-    std::map<std::vector<int64_t>, std::pair<int, int>> tune_cache_;   // conv signature -> (tile, splitk)
     std::map<std::vector<int64_t>, std::unique_ptr<PlanInstance>> plans_;
     // Least-recently-used order of the plan keys (front = oldest).  A server that sees many distinct batch sizes would otherwise keep
     // one set of activation buffers + one hipGraph per size forever; beyond IE_MAX_PLANS (default 8) the oldest instance is freed
-    // (its autotune results stay in tune_cache_, so re-creating it is cheap).
+    // (its kernel choices stay in the tune cache, so re-creating it is cheap).
     std::vector<std::vector<int64_t>> lru_;
     size_t max_plans_ = 8;
     PlanInstance* current_ = nullptr;
-    std::unique_ptr<CopyPool> copy_pool_;
-    void* pinned_ = nullptr;           // pinned host staging ring for H2D/D2H
+    void* pinned_ = nullptr;           // pinned host staging for D2H results
     size_t pinned_bytes_ = 0;
-    std::mutex mu_;
+    int64_t pipelined_calls_ = 0;
+    int last_chunks_ = 1, last_head_steps_ = 0;
+    double last_forward_ms_ = 0;
 };
 
 // Device queries behind IsCudaAvailable / GetDeviceCount / GetDeviceInfo / GetMemoryInfo

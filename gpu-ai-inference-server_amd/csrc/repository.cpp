@@ -1,6 +1,9 @@
 #include "repository.h"
 
 #include <algorithm>
+#include <cctype>
+#include <cstdlib>
+#include <cstring>
 #include <filesystem>
 
 namespace fs = std::filesystem;
@@ -42,7 +45,19 @@ bool Repository::Scan() {
             // a comparator that throws for some pairs and not others is not a strict weak order; decide once
             bool numeric = true;
             for (auto& v : vs) { try { (void)std::stoi(v); } catch (const std::exception&) { numeric = false; } }
-            if (numeric) std::stable_sort(vs.begin(), vs.end(), version_before);
+            // IE_VERSION_ORDER=go: the unchanged Go server picks the config.json of the LEXICOGRAPHICALLY last all-digit directory
+            // (server/main.go:640-655: sort.Strings over isNumeric names), e.g. "2" over "10", while the reference's C++ side -- and
+            // this engine by default -- loads the numerically latest (model_repository.cpp:45-53).  With versions >= 10 the two
+            // disagree about which version "latest" is; this switch makes the engine follow the Go side's rule.
+            const char* ord = std::getenv("IE_VERSION_ORDER");
+            if (ord && (std::strcmp(ord, "go") == 0 || std::strcmp(ord, "lexicographic") == 0)) {
+                std::stable_sort(vs.begin(), vs.end(), [](const std::string& a, const std::string& b) {
+                    auto digits = [](const std::string& v) { return !v.empty() && std::all_of(v.begin(), v.end(), [](unsigned char c) { return std::isdigit(c) != 0; }); };
+                    const bool da = digits(a), db = digits(b);
+                    if (da != db) return da;                  // Go only considers all-digit names
+                    return a > b;
+                });
+            } else if (numeric) std::stable_sort(vs.begin(), vs.end(), version_before);
             else std::sort(vs.begin(), vs.end(), std::greater<std::string>());
             if (!vs.empty()) found[md.path().filename().string()] = vs;
         }

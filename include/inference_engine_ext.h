@@ -53,6 +53,13 @@ bool EngineGetBatcherStats(ModelHandle handle, int64_t* device_batches, int64_t*
  * were sharded.  Enable with IE_GPUS=<n> or config.json {"gpus": n} (devices device_id .. device_id+n-1, clipped to the device count)
  * or IE_SHARD_DEVICES=<id,id,...> (explicit list, ids may repeat).  Needs a graph with a symbolic batch axis. */
 bool EngineGetShardStats(ModelHandle handle, int* num_shards, int64_t* sharded_calls);
+/* JSON description of a loaded model's runtime: precision, execution lanes (config.json "instance_count") and shard replicas with
+ * their devices and which lanes share a weight allocation, the high-water mark of concurrent requests, the RCCL weight broadcast
+ * done at load (ranks, bytes, milliseconds), HIP-event device time of the forwards with the planner's algorithmic TFLOP/s and GB/s
+ * against the gfx950 peaks, and counters of the pipelined host path.  with_checksums != 0 adds an FNV-1a checksum of every lane's
+ * packed weight blob as it sits in HBM (waits for in-flight requests).  The one-line form of the same facts is what
+ * ModelGetMetadata() returns in `description`.  malloc'd, release with FreeErrorMessage(). */
+char* EngineGetRuntimeInfo(ModelHandle handle, int with_checksums, ErrorMessage* error);
 /* result = a + b on the GPU for host arrays (the reference's VectorAdd smoke test, cuda_utils.cu:59-149). */
 bool EngineVectorAdd(const float* a, const float* b, float* result, size_t n, ErrorMessage* error);
 

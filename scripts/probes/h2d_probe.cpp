@@ -70,6 +70,35 @@ int main() {
             }
             std::printf("%zu MB memcpy pageable->pinned, %2d threads (spawned): %.3f ms (%.1f GB/s)\n", mb, nt, best * 1e3, n / best / 1e9);
         }
+        // (a2) a FRESH pageable buffer per call (the Go binding C.mallocs its payload per request, inference_binding.go:590-640):
+        //      how long does the call itself block, and how long until the data is in HBM?
+        for (int rep = 0; rep < 4; ++rep) {
+            char* fresh = static_cast<char*>(std::malloc(n));
+            std::memset(fresh, rep, n);
+            double t0 = now();
+            CK(hipMemcpyAsync(dev, fresh, n, hipMemcpyHostToDevice, st));
+            double t1 = now();
+            CK(hipStreamSynchronize(st));
+            double t2 = now();
+            std::printf("%zu MB FRESH pageable hipMemcpyAsync: call %.3f ms, done after %.3f ms (%.1f GB/s)\n", mb, (t1 - t0) * 1e3, (t2 - t0) * 1e3, n / (t2 - t0) / 1e9);
+            std::free(fresh);
+        }
+        // (a3) the same in 4 chunks (what a pipelined ModelInfer would issue)
+        for (int rep = 0; rep < 3; ++rep) {
+            char* fresh = static_cast<char*>(std::malloc(n));
+            std::memset(fresh, rep, n);
+            double t0 = now();
+            double tc[4];
+            for (int c = 0; c < 4; ++c) {
+                CK(hipMemcpyAsync(static_cast<char*>(dev) + c * (n / 4), fresh + c * (n / 4), n / 4, hipMemcpyHostToDevice, st));
+                tc[c] = now() - t0;
+            }
+            CK(hipStreamSynchronize(st));
+            double t2 = now();
+            std::printf("%zu MB FRESH pageable in 4 chunks: calls return at %.3f %.3f %.3f %.3f ms, done after %.3f ms\n", mb, tc[0] * 1e3, tc[1] * 1e3, tc[2] * 1e3,
+                        tc[3] * 1e3, (t2 - t0) * 1e3);
+            std::free(fresh);
+        }
         // (e) D2H small: 128 KB pinned
         for (int rep = 0; rep < 3; ++rep) {
             double t0 = now();

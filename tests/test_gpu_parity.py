@@ -1229,3 +1229,170 @@ def test_two_input_graph_orders_inputs_by_graph_index(mgr):
             m.Infer([bad_a, bad_b], outs)
     finally:
         mgr.UnloadModel("mini_two_input")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Lanes (instance_count), in-process RCCL weight broadcast, pipelined host path, tuning off the request path
+# ---------------------------------------------------------------------------------------------------------------------
+def test_instance_count_runs_two_requests_side_by_side(densenet_repo, tmp_path):
+    """config.json "instance_count": 2 (the field model.h:63 carries and the reference never reads): two execution lanes on the
+    device sharing one weight blob; two threads calling ModelInfer overlap (the lane pool's high-water mark reaches 2) and every
+    call returns exactly what the serial run returned."""
+    root = _with_precision_config(densenet_repo, tmp_path, ',"instance_count":2')
+    m = B.CreateModel(os.path.join(root, "densenet_onnx", "1"), "densenet_onnx")
+    try:
+        info = B.RuntimeInfo(m)
+        assert info["lanes"] == 2 and info["shards"] == 1 and info["lane_shares_weights_with"] == [0, 0] and not info["rccl"]["used"]
+        xs = [models.synthetic_input((8, 3, 224, 224), stream=f"lane{i}") for i in range(2)]
+        serial = [infer(m, "", "data_0", x, "fc6_1", [8, 1000, 1, 1])[0].copy() for x in xs]
+        for lane_warm in range(2):          # the second lane plans B=8 on its first use
+            infer(m, "", "data_0", xs[0], "fc6_1", [8, 1000, 1, 1])
+        outs = {0: [], 1: []}
+        errs = []
+        gate = threading.Barrier(2)
+
+        def worker(i):
+            try:
+                gate.wait()
+                for _ in range(12):
+                    outs[i].append(infer(m, "", "data_0", xs[i], "fc6_1", [8, 1000, 1, 1])[0].copy())
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+        ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert not errs, errs
+        for i in range(2):
+            for y in outs[i]:
+                np.testing.assert_array_equal(y, serial[i])
+        assert B.RuntimeInfo(m)["max_in_flight"] == 2
+        assert "mi355x-engine precision=fp32 lanes=2" in m.GetMetadata().Description
+    finally:
+        m.Destroy()
+
+
+def test_rccl_weight_broadcast_to_a_private_replica(densenet_repo):
+    """The in-process sharding fills a replica that owns its weights with ONE ncclBroadcast of the packed blob at load.
+    On the 1-GPU box: IE_SHARD_DEVICES=0,0 with IE_SHARD_PRIVATE_WEIGHTS=1 gives the replica its own (zeroed, never uploaded)
+    allocation on device 0; RCCL (one rank, out-of-place broadcast) is what moves the 32 MB.  The replica's blob checksum in HBM
+    must equal the primary's, and the sharded answer must equal the unsharded one."""
+    path = os.path.join(densenet_repo, "densenet_onnx", "1")
+    x = models.synthetic_input((8, 3, 224, 224), stream="rccl")
+    outs = [B.OutputConfig("fc6_1", Shape=[8, 1000, 1, 1], DataType="FLOAT32")]
+    m = B.CreateModel(path, "densenet_onnx")
+    try:
+        y1 = m.Infer([B.TensorData("data_0", B.DataTypeFloat32, B.Shape([8, 3, 224, 224]), x)], outs)[0].Data.copy()
+        c1 = B.RuntimeInfo(m, checksums=True)["weight_checksums"]
+    finally:
+        m.Destroy()
+
+    def go():
+        m2 = B.CreateModel(path, "densenet_onnx")
+        try:
+            info = B.RuntimeInfo(m2, checksums=True)
+            y2 = m2.Infer([B.TensorData("data_0", B.DataTypeFloat32, B.Shape([8, 3, 224, 224]), x)], outs)[0].Data.copy()
+            return info, y2, B.ShardStats(m2)
+        finally:
+            m2.Destroy()
+    info, y2, st = _run_with_env(dict(IE_SHARD_DEVICES="0,0", IE_SHARD_PRIVATE_WEIGHTS="1"), go)
+    assert info["lanes"] == 2 and info["shards"] == 2 and info["lane_shares_weights_with"] == [0, 1]
+    r = info["rccl"]
+    assert r["used"] and r["ranks"] == 1 and r["weight_owners"] == 2 and r["bytes"] > 30e6 and r["broadcast_ms"] > 0
+    assert info["weight_checksums"][0] == info["weight_checksums"][1] == c1[0]
+    assert st == (2, 1)
+    assert rel_err(y2, y1) < 2e-5
+    # without private weights a same-device replica shares the primary's blob: nothing to broadcast
+    info3 = _run_with_env(dict(IE_SHARD_DEVICES="0,0"), lambda: (lambda mm: (B.RuntimeInfo(mm), mm.Destroy())[0])(B.CreateModel(path, "densenet_onnx")))
+    assert info3["lane_shares_weights_with"] == [0, 0] and not info3["rccl"]["used"]
+
+
+def test_pipelined_host_path_matches_single_shot(densenet_repo):
+    """ModelInfer uploads a batch in image ranges and runs the first plan steps per range while the next range uploads; the rest runs
+    once on the whole batch.  Same arithmetic, other tile choices for the per-range launches: equal to the single-shot path up to
+    fp32 summation order; B=32 FLOAT32 and UINT8 payloads, plus a ragged short payload."""
+    path = os.path.join(densenet_repo, "densenet_onnx", "1")
+    x = models.synthetic_input((32, 3, 224, 224), stream="pipe")
+    xb = np.clip(x * 255.0, 0, 255).astype(np.uint8)
+    outs = [B.OutputConfig("fc6_1", Shape=[32, 1000, 1, 1], DataType="FLOAT32")]
+
+    def run(expect_chunks):
+        m = B.CreateModel(path, "densenet_onnx")
+        try:
+            yf = m.Infer([B.TensorData("data_0", B.DataTypeFloat32, B.Shape([32, 3, 224, 224]), x)], outs)[0].Data.copy()
+            info = B.RuntimeInfo(m)
+            yu = m.Infer([B.TensorData("data_0", B.DataTypeUint8, B.Shape([32, 3, 224, 224]), xb)], outs)[0].Data.copy()
+            short = x.reshape(-1)[:3 * 224 * 224 * 13 + 1000]                     # ends inside image 13: zero-extended
+            ys = m.Infer([B.TensorData("data_0", B.DataTypeFloat32, B.Shape([32, 3, 224, 224]), short)], outs)[0].Data.copy()
+            assert info["last_chunks"] == expect_chunks, info
+            if expect_chunks > 1:
+                assert info["last_head_steps"] >= 2 and info["pipelined_calls"][0] >= 1
+            return yf, yu, ys
+        finally:
+            m.Destroy()
+    yf, yu, ys = run(4)
+    yf0, yu0, ys0 = _run_with_env(dict(IE_PIPELINE_CHUNKS="0"), lambda: run(1))
+    assert rel_err(yf, yf0) < 2e-5 and rel_err(yu, yu0) < 2e-5 and rel_err(ys, ys0) < 2e-5
+    assert rel_err(ys.reshape(32, 1000)[:13], yf.reshape(32, 1000)[:13]) < 2e-5        # whole images before the cut are unaffected
+    assert np.abs(ys.reshape(32, 1000)[14:] - ys.reshape(32, 1000)[14]).max() < 1e-5   # all-zero images give one common answer
+
+
+def test_dynamic_batcher_feeds_the_sharder(densenet_repo):
+    """A coalesced batch is cut over the shard replicas like a single large request (round 1: the two were mutually exclusive)."""
+    x = models.synthetic_input((8, 3, 224, 224), stream="batcher")
+    path = os.path.join(densenet_repo, "densenet_onnx", "1")
+    ref_m = B.CreateModel(path, "densenet_onnx")
+    ref = np.stack([infer(ref_m, "", "data_0", x[i:i + 1], "fc6_1", [1, 1000, 1, 1])[0].reshape(1000) for i in range(8)])
+    ref_m.Destroy()
+
+    def go():
+        m = B.CreateModel(path, "densenet_onnx")
+        try:
+            assert B.BatcherStats(m)["max_batch"] == 8 and B.ShardStats(m)[0] == 2
+            out = [None] * 8
+            errs = []
+
+            def call(i):
+                try:
+                    out[i] = infer(m, "", "data_0", x[i:i + 1], "fc6_1", [1, 1000, 1, 1])[0].reshape(1000)
+                except Exception as e:  # noqa: BLE001
+                    errs.append(e)
+            ts = [threading.Thread(target=call, args=(i,)) for i in range(8)]
+            [t.start() for t in ts]
+            [t.join() for t in ts]
+            assert not errs, errs
+            return np.stack(out), B.BatcherStats(m), B.ShardStats(m)
+        finally:
+            m.Destroy()
+    out, bs, ss = _run_with_env(dict(IE_DYNAMIC_BATCH="8", IE_BATCH_WINDOW_US="200000", IE_SHARD_DEVICES="0,0"), go)
+    assert bs["coalesced_requests"] == 8 and bs["device_batches"] < 8
+    assert ss[1] >= 1                                  # at least one coalesced batch had >= 2 rows and was cut over both replicas
+    assert rel_err(out, ref) < 2e-5
+
+
+def test_requests_never_wait_for_a_kernel_search(tmp_path):
+    """The exhaustive kernel search runs at load (declared shape + "tune_batches") and persists beside the model; a request with a
+    batch size nobody tuned for takes the cached choice of the nearest pixel count or the planner's default -- the cache file is not
+    touched by requests, and a second process finds it."""
+    mb = models.densenet("N", growth=16, blocks=(2, 2), stem=32, image=64, classes=10, seed=11)
+    path = models.write_repo(str(tmp_path), "tuned", mb, config_json='{"tune_batches": [4]}')
+    cache = os.path.join(path, ".ie_tune.fp32.txt")
+    m = B.CreateModel(path, "tuned")
+    try:
+        assert os.path.exists(cache)
+        lines = open(cache).read().splitlines()
+        assert lines[0].startswith("# ie-tune-v2 ") and len(lines) > 4
+        stamp = (os.stat(cache).st_mtime_ns, open(cache).read())
+        for b in (4, 5, 3, 16):
+            x = models.synthetic_input((b, 3, 64, 64), stream=f"tune{b}")
+            y, _ = infer(m, "", "data_0", x, "fc6_1", [b, 10, 1, 1])
+            yo = O.run(O.load_model(models.densenet(b, growth=16, blocks=(2, 2), stem=32, image=64, classes=10, seed=11)), {"data_0": x})["fc6_1"]
+            assert rel_err(y, yo) < RTOL
+        assert (os.stat(cache).st_mtime_ns, open(cache).read()) == stamp
+        assert not [f for f in os.listdir(path) if ".tmp" in f]          # written through a temporary + rename, none left behind
+    finally:
+        m.Destroy()
+    m2 = B.CreateModel(path, "tuned")           # same process, fresh model: choices come from the file, nothing is re-searched
+    try:
+        assert (os.stat(cache).st_mtime_ns, open(cache).read()) == stamp
+    finally:
+        m2.Destroy()
