@@ -293,6 +293,59 @@ class Model:
             for p in to_free:
                 _libc.free(p)
 
+    def InferTimed(self, inputs: Sequence[TensorData], outputConfigs: Sequence[OutputConfig], iters: int) -> list:
+        """Seconds spent INSIDE the ModelInfer C call, per call, for `iters` calls.
+
+        Every iteration marshals exactly like Infer() / the Go binding does (fresh C.malloc'ed payload and output buffers, payload
+        copied in, buffers freed afterwards: inference_binding.go:590-734) but only the C-ABI call itself is timed, i.e. what the
+        engine is responsible for; Infer()'s wall time adds the binding's own malloc + copy, which the build does not change."""
+        import time
+        L = lib()
+        times = []
+        for _ in range(iters):
+            to_free = []
+            try:
+                cin = (CTensorData * len(inputs))()
+                outs = [(oc.Name.encode(), list(oc.Shape) or list(oc.Dims)) for oc in outputConfigs]
+                cout = (CTensorData * max(len(outs), 1))()
+                keep = []
+                for i, t in enumerate(inputs):
+                    arr = np.ascontiguousarray(t.Data, dtype=np.float32 if t.DataType == DataTypeFloat32 else np.uint8).ravel()
+                    nm = t.Name.encode()
+                    dims = (C.c_int64 * len(t.Shape.Dims))(*t.Shape.Dims)
+                    keep += [nm, dims]
+                    buf = _libc.malloc(max(arr.nbytes, 1))
+                    to_free.append(buf)
+                    C.memmove(buf, arr.ctypes.data, arr.nbytes)
+                    cin[i].name = nm
+                    cin[i].data_type = t.DataType
+                    cin[i].shape.dims = C.cast(dims, C.POINTER(C.c_int64))
+                    cin[i].shape.num_dims = len(t.Shape.Dims)
+                    cin[i].data = buf
+                    cin[i].data_size = arr.nbytes
+                for i, (nm, shape) in enumerate(outs):
+                    dims = (C.c_int64 * len(shape))(*shape)
+                    keep += [nm, dims]
+                    nbytes = 4 * int(np.prod(shape))
+                    buf = _libc.malloc(max(nbytes, 1))
+                    to_free.append(buf)
+                    cout[i].name = nm
+                    cout[i].data_type = DataTypeFloat32
+                    cout[i].shape.dims = C.cast(dims, C.POINTER(C.c_int64))
+                    cout[i].shape.num_dims = len(shape)
+                    cout[i].data = buf
+                    cout[i].data_size = nbytes
+                err = C.c_void_p()
+                t0 = time.perf_counter()
+                ok = L.ModelInfer(self.handle, cin, len(inputs), cout, len(outs), C.byref(err))
+                times.append(time.perf_counter() - t0)
+                if not ok:
+                    raise RuntimeError("inference failed: " + _take_error(err))
+            finally:
+                for p_ in to_free:
+                    _libc.free(p_)
+        return times
+
     def GetMetadata(self) -> ModelMetadata:
         L = lib()
         p = L.ModelGetMetadata(self.handle)
