@@ -388,6 +388,10 @@ void DeviceModel::EnsurePipeline(PlanInstance& pi, bool allow_tune) {
                 a.w_off != b.w_off || a.bias_off != b.bias_off || a.pre_scale_off != b.pre_scale_off || a.pre_shift_off != b.pre_shift_off)
                 return false;
         }
+        // Tensors that cross from the head into the tail: a tail step reads a view that no earlier TAIL step has written.  Range c+1
+        // runs its head after range c finished its own, so inside the head a range may overwrite rows of earlier ranges only in
+        // buffers whose content is dead at the boundary.  Rows of different ranges are disjoint when every tensor the head puts into
+        // a buffer has the same image stride; so: every buffer holding a crossing tensor must see ONE image stride during the head.
         std::map<int, int64_t> head_stride;       // buffer -> image stride of the head's tensors in it (-1 = mixed)
         auto note = [&](const View& v) {
             auto f = head_stride.find(v.buf);
@@ -395,12 +399,29 @@ void DeviceModel::EnsurePipeline(PlanInstance& pi, bool allow_tune) {
             else if (f->second != image_stride(v)) f->second = -1;
         };
         for (size_t i = 0; i < h; ++i) { note(full.steps[i].in); note(full.steps[i].out); if (full.steps[i].has_in2) note(full.steps[i].in2); }
-        for (size_t i = h; i < full.steps.size(); ++i)
-            for (const View* v : {&full.steps[i].in, full.steps[i].has_in2 ? &full.steps[i].in2 : nullptr}) {
-                if (!v) continue;
-                auto f = head_stride.find(v->buf);
-                if (f != head_stride.end() && f->second == -1) return false;
+        std::vector<const View*> tail_written;
+        auto covered = [&](const View& v) {      // the union of the tail's earlier writes (concat slices) spans the view's channels
+            int64_t pos = v.c_off;
+            const int64_t end = v.c_off + v.c;
+            bool progress = true;
+            while (pos < end && progress) {
+                progress = false;
+                for (const View* w : tail_written)
+                    if (w->buf == v.buf && w->nchw == v.nchw && image_stride(*w) == image_stride(v) && w->c_off <= pos && w->c_off + w->c > pos) {
+                        pos = w->c_off + w->c;
+                        progress = true;
+                    }
             }
+            return pos >= end;
+        };
+        for (size_t i = h; i < full.steps.size(); ++i) {
+            for (const View* v : {&full.steps[i].in, full.steps[i].has_in2 ? &full.steps[i].in2 : nullptr}) {
+                if (!v || covered(*v)) continue;
+                auto f = head_stride.find(v->buf);
+                if (f != head_stride.end() && (f->second == -1 || f->second != image_stride(*v))) return false;
+            }
+            tail_written.push_back(&full.steps[i].out);
+        }
         return true;
     };
     while (head > 0 && !valid(head)) --head;

@@ -154,7 +154,7 @@ private:
     bool use_graph_ = true;
     bool autotune_ = true;
     bool tune_on_demand_ = false;      // IE_TUNE_ON_DEMAND=1: search on the request path too (round-1 behaviour)
-    int pipeline_chunks_ = 4;          // IE_PIPELINE_CHUNKS (0/1 = off)
+    int pipeline_chunks_ = 2;          // IE_PIPELINE_CHUNKS (0/1 = off); measured: 2 ranges beat 4 and 8 (per-range launches cost more than they hide)
     int pipeline_head_ = -1;           // IE_PIPELINE_HEAD: steps run per chunk (-1 = modelled)
     bool two_pass_splitk_ = true;      // IE_SPLITK_IN_LAUNCH=1 selects the in-launch combine instead of the reduce kernel
     std::map<std::vector<int64_t>, std::unique_ptr<PlanInstance>> plans_;

@@ -1329,7 +1329,7 @@ def test_pipelined_host_path_matches_single_shot(densenet_repo):
             return yf, yu, ys
         finally:
             m.Destroy()
-    yf, yu, ys = run(4)
+    yf, yu, ys = run(2)
     yf0, yu0, ys0 = _run_with_env(dict(IE_PIPELINE_CHUNKS="0"), lambda: run(1))
     assert rel_err(yf, yf0) < 2e-5 and rel_err(yu, yu0) < 2e-5 and rel_err(ys, ys0) < 2e-5
     assert rel_err(ys.reshape(32, 1000)[:13], yf.reshape(32, 1000)[:13]) < 2e-5        # whole images before the cut are unaffected
