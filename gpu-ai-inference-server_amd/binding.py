@@ -69,7 +69,7 @@ ABI_SYMBOLS = [
     "ModelLoad", "ModelUnload",
 ]
 EXT_SYMBOLS = ["EngineDescribeModel", "EnginePrepare", "EngineRunPrepared", "EngineSynchronize", "EngineGetStream",
-               "EngineProfile", "EngineGetWeightBlob", "EngineWeightsUpdated", "EngineGetPrecision", "EngineMemcpy", "EngineMfmaPeak", "EngineGetBatcherStats", "EngineGetShardStats", "EngineGetRuntimeInfo", "EngineVectorAdd"]
+               "EngineProfile", "EngineGetWeightBlob", "EngineWeightsUpdated", "EngineGetPrecision", "EngineMemcpy", "EngineMfmaPeak", "EngineGetBatcherStats", "EngineGetShardStats", "EngineGetRuntimeInfo", "EngineE4m3RoundTrip", "EnginePlanWeights", "EngineVectorAdd"]
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -117,6 +117,8 @@ def lib() -> C.CDLL:
             "EngineGetBatcherStats": (C.c_bool, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
             "EngineGetShardStats": (C.c_bool, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
             "EngineGetRuntimeInfo": (C.c_void_p, [vp, C.c_int, C.POINTER(C.c_void_p)]),
+            "EnginePlanWeights": (C.c_void_p, [cp, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)]),
+            "EngineE4m3RoundTrip": (C.c_bool, [vp, vp, vp, C.c_size_t, C.c_float, C.POINTER(C.c_void_p)]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)   # AttributeError here = symbol missing from the .so
@@ -559,7 +561,7 @@ def WeightsUpdated(model: Model) -> None:
 
 
 def Precision(model: Model) -> str:
-    return {0: "fp32", 1: "fp16"}.get(int(lib().EngineGetPrecision(model.handle)), "unloaded")
+    return {0: "fp32", 1: "fp16", 2: "fp8"}.get(int(lib().EngineGetPrecision(model.handle)), "unloaded")
 
 
 def ShardStats(model: Model) -> tuple:
@@ -568,6 +570,30 @@ def ShardStats(model: Model) -> tuple:
     if not lib().EngineGetShardStats(model.handle, C.byref(n), C.byref(calls)):
         raise RuntimeError("shard stats unavailable")
     return int(n.value), int(calls.value)
+
+
+def PlanWeights(path: str, batch: int = 1) -> np.ndarray:
+    """Host-only: the packed fp32 weight blob the plan steps' offsets index into."""
+    n = C.c_size_t()
+    err = C.c_void_p()
+    p = lib().EnginePlanWeights(path.encode(), int(batch), C.byref(n), C.byref(err))
+    if not p:
+        raise RuntimeError(_take_error(err))
+    try:
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(n.value,)).copy()
+    finally:
+        lib().FreeErrorMessage(p)
+
+
+def E4m3RoundTrip(x: np.ndarray, scale: float = 1.0):
+    """(codes uint8, decoded float32) of the device's e4m3 conversion of x / scale."""
+    x = np.ascontiguousarray(x, np.float32).ravel()
+    dst = np.empty_like(x)
+    codes = np.empty(x.size, np.uint8)
+    err = C.c_void_p()
+    if not lib().EngineE4m3RoundTrip(x.ctypes.data, dst.ctypes.data, codes.ctypes.data, x.size, float(scale), C.byref(err)):
+        raise RuntimeError(_take_error(err))
+    return codes, dst
 
 
 def RuntimeInfo(model: Model, checksums: bool = False) -> dict:

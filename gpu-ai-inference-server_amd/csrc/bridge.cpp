@@ -360,8 +360,9 @@ bool ModelObj::Load() {
                     if (const char* e = std::getenv("IE_PRECISION")) want = e;
                     for (auto& ch : want) ch = char(std::tolower(static_cast<unsigned char>(ch)));
                     if (want == "fp16" || want == "f16" || want == "half" || want == "float16") prec = ie::Precision::F16;
+                    else if (want == "fp8" || want == "f8" || want == "e4m3" || want == "float8") prec = ie::Precision::F8;
                     else if (!want.empty() && want != "fp32" && want != "f32" && want != "float32" && want != "float") {
-                        SetError("ONNX model loading error: unsupported precision '" + want + "' (fp32 or fp16)");
+                        SetError("ONNX model loading error: unsupported precision '" + want + "' (fp32, fp16 or fp8)");
                         break;
                     }
                 }
@@ -371,7 +372,7 @@ bool ModelObj::Load() {
                 u8_bias = conf.uint8_bias;
                 ie::DeviceModelOptions opt;
                 opt.precision = prec;
-                opt.tune_cache_path = path + "/.ie_tune." + (prec == ie::Precision::F16 ? "fp16" : "fp32") + ".txt";
+                opt.tune_cache_path = path + "/.ie_tune." + (prec == ie::Precision::F16 ? "fp16" : (prec == ie::Precision::F8 ? "fp8" : "fp32")) + ".txt";
                 auto primary = std::make_unique<ie::DeviceModel>(parsed, device_id, opt);
                 primary->SetU8Transform(u8_scale, u8_bias);
                 // Plan + tune at load, off the request path (like Ort::Session's constructor, which also rejects unsupported graphs
@@ -1053,8 +1054,8 @@ std::string describe_runtime(ModelObj& M, bool json, bool checksums = false) {
     { std::lock_guard<std::mutex> g(M.acct_mu); ms = M.acct_ms; fl = M.acct_flops; by = M.acct_bytes; fw = M.acct_forwards; im = M.acct_images; }
     const bool up = M.loaded.load() && !M.lanes.empty();
     const ie::Precision prec = up ? M.lanes[0]->precision() : ie::Precision::F32;
-    const char* pname = prec == ie::Precision::F16 ? "fp16" : "fp32";
-    const double mfma_peak = prec == ie::Precision::F16 ? 2500.0 : 157.3;     // TFLOP/s dense, gfx950
+    const char* pname = prec == ie::Precision::F16 ? "fp16" : (prec == ie::Precision::F8 ? "fp8" : "fp32");
+    const double mfma_peak = prec == ie::Precision::F16 ? 2500.0 : (prec == ie::Precision::F8 ? 5000.0 : 157.3);     // TFLOP/s dense, gfx950
     const double tflops = ms > 0 ? fl / (ms * 1e-3) / 1e12 : 0, gbs = ms > 0 ? by / (ms * 1e-3) / 1e9 : 0;
     int max_in_flight;
     { std::lock_guard<std::mutex> g(M.pool.mu); max_in_flight = M.pool.max_in_flight; }
@@ -1083,6 +1084,15 @@ std::string describe_runtime(ModelObj& M, bool json, bool checksums = false) {
         o << ",\"pipelined_calls\":[";
         for (size_t i = 0; i < M.lanes.size(); ++i) o << (i ? "," : "") << M.lanes[i]->pipelined_calls();
         o << "],\"last_chunks\":" << M.lanes[0]->last_chunks() << ",\"last_head_steps\":" << M.lanes[0]->last_head_steps();
+    }
+    if (up && prec == ie::Precision::F8) {
+        // fp8 mode: the calibrated per-tensor scales (index = plan step that writes the tensor; real value = e4m3 code x scale)
+        const auto& W = *M.lanes[0]->shared_weights();
+        o << ",\"f8_ready\":" << (W.f8_ready ? "true" : "false") << ",\"f8_act_scales\":[";
+        o.precision(9);
+        for (size_t i = 0; i < W.act_scale.size(); ++i) o << (i ? "," : "") << W.act_scale[i];
+        o << "]";
+        o.precision(6);
     }
     if (up && checksums) {
         // FNV-1a of every lane's packed fp32 blob as it sits in HBM (a replica filled by the RCCL broadcast must equal the primary)
@@ -1245,11 +1255,36 @@ char* EngineDescribeModel(const char* path, int batch, ErrorMessage* error) {
             if (const char* e = std::getenv("IE_PRECISION")) {
                 std::string w = e;
                 if (w == "fp16" || w == "f16" || w == "half") prec = ie::Precision::F16;
+                else if (w == "fp8" || w == "f8" || w == "e4m3") prec = ie::Precision::F8;
             }
             o << ",\"plan\":" << ie::PlanToJson(ie::BuildPlan(m, shapes, prec));
         }
         o << "}";
         return dup_cstr(o.str());
+    } catch (const std::exception& e) { set_error(error, e.what()); return nullptr; }
+    catch (...) { set_error(error, "unknown error"); return nullptr; }
+}
+
+float* EnginePlanWeights(const char* path, int batch, size_t* count, ErrorMessage* error) {
+    if (!path || !count || batch <= 0) { set_error(error, "Invalid parameters"); return nullptr; }
+    try {
+        std::string file = path;
+        std::error_code ec;
+        if (std::filesystem::is_directory(file, ec)) file += "/model.onnx";
+        if (!std::filesystem::exists(file, ec)) { set_error(error, "ONNX model file not found: " + file); return nullptr; }
+        ie::OnnxModel m = ie::LoadOnnxFile(file);
+        std::vector<std::vector<int64_t>> shapes;
+        for (auto& vi : m.inputs) {
+            std::vector<int64_t> s = vi.dims;
+            for (size_t k = 0; k < s.size(); ++k) if (s[k] <= 0) s[k] = (k == 0 ? batch : 1);
+            shapes.push_back(s);
+        }
+        ie::Plan p = ie::BuildPlan(m, shapes, ie::Precision::F32);
+        float* out = static_cast<float*>(std::malloc(std::max<size_t>(p.weights.size(), 1) * sizeof(float)));
+        if (!out) { set_error(error, "out of memory"); return nullptr; }
+        std::memcpy(out, p.weights.data(), p.weights.size() * sizeof(float));
+        *count = p.weights.size();
+        return out;
     } catch (const std::exception& e) { set_error(error, e.what()); return nullptr; }
     catch (...) { set_error(error, "unknown error"); return nullptr; }
 }
@@ -1421,6 +1456,23 @@ char* EngineGetRuntimeInfo(ModelHandle handle, int with_checksums, ErrorMessage*
         return dup_cstr(describe_runtime(M, true, false));
     } catch (const std::exception& e) { set_error(error, e.what()); return nullptr; }
     catch (...) { set_error(error, "unknown error"); return nullptr; }
+}
+
+bool EngineE4m3RoundTrip(const float* src, float* dst, unsigned char* codes, size_t n, float scale, ErrorMessage* error) {
+    if (!src || !dst || !(scale > 0.f)) { set_error(error, "Invalid parameters"); return false; }
+    if (ie::HipDeviceCount() <= 0) { set_error(error, "No HIP device available"); return false; }
+    if (n == 0) return true;
+    float *ds = nullptr, *dd = nullptr;
+    unsigned char* dc = nullptr;
+    bool ok = hipMalloc(reinterpret_cast<void**>(&ds), n * 4) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&dd), n * 4) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void**>(&dc), n) == hipSuccess && hipMemcpy(ds, src, n * 4, hipMemcpyHostToDevice) == hipSuccess &&
+              ie::LaunchE4m3RoundTrip(ds, dd, dc, scale, int64_t(n), nullptr) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+              hipMemcpy(dst, dd, n * 4, hipMemcpyDeviceToHost) == hipSuccess && (!codes || hipMemcpy(codes, dc, n, hipMemcpyDeviceToHost) == hipSuccess);
+    if (ds) (void)hipFree(ds);
+    if (dd) (void)hipFree(dd);
+    if (dc) (void)hipFree(dc);
+    if (!ok) { (void)hipGetLastError(); set_error(error, "HIP error in EngineE4m3RoundTrip"); }
+    return ok;
 }
 
 bool EngineVectorAdd(const float* a, const float* b, float* result, size_t n, ErrorMessage* error) {

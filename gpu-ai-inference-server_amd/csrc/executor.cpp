@@ -28,7 +28,8 @@ TensorArg make_arg(const PlanInstance& pi, const View& v) {
     char* base = reinterpret_cast<char*>(pi.buffers.at(size_t(v.buf)));
     t.n = int(v.n); t.h = int(v.h); t.w = int(v.w); t.c = int(v.c);
     t.f16 = v.f16 ? 1 : 0;
-    const int64_t esize = v.f16 ? 2 : 4;
+    t.f8 = v.f8 ? 1 : 0;
+    const int64_t esize = v.esize();
     if (v.nchw) {
         t.sw = 1; t.sh = v.w; t.sc = v.h * v.w; t.sn = v.c * v.h * v.w;
         t.p = reinterpret_cast<float*>(base + pi.batch_off * t.sn * esize);
@@ -81,6 +82,7 @@ DeviceWeights::~DeviceWeights() {
     if (d_weights16) (void)hipFree(d_weights16);
     if (d_weights_frag) (void)hipFree(d_weights_frag);
     if (d_weights8) (void)hipFree(d_weights8);
+    if (d_f8_aux) (void)hipFree(d_f8_aux);
 }
 
 namespace {
@@ -133,6 +135,7 @@ DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id, 
         if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsWs3();
         if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsStem();
         if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsDirect();
+        if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsF8();
     });
     check(g_kernels_err, "InitKernels");
     if (opt.share) {
@@ -218,9 +221,24 @@ void DeviceModel::BuildInstance(PlanInstance& pi, const std::vector<std::vector<
             } else {
                 check(hipMemset(w_->d_weights, 0, w_->weight_floats * sizeof(float)), "hipMemset(weights)");
             }
-            if (precision_ == Precision::F16) {
+            if (precision_ == Precision::F16 || precision_ == Precision::F8) {
                 check(hipMalloc(&w_->d_weights16, std::max<size_t>(w_->weight_floats, 8) * 2), "hipMalloc(weights16)");
                 w_->device_bytes += w_->weight_floats * 2;
+                if (precision_ == Precision::F8) {
+                    check(hipMalloc(&w_->d_weights8, std::max<size_t>(w_->weight_floats, 16)), "hipMalloc(weights8)");
+                    check(hipMemset(w_->d_weights8, 0, std::max<size_t>(w_->weight_floats, 16)), "hipMemset(weights8)");
+                    w_->device_bytes += w_->weight_floats;
+                    int64_t aux = 0;
+                    for (size_t i = 0; i < pi.plan.steps.size(); ++i) {
+                        const Step& st = pi.plan.steps[i];
+                        if (st.kind != StepKind::Conv || st.algo != ConvAlgo::IgemmF8) continue;
+                        w_->f8_convs.push_back({int(i), st.w_off, int(st.out.c), int(st.kh * st.kw * st.in.c), st.in_src, aux});
+                        aux += 2 * ((st.out.c + 3) / 4 * 4);
+                    }
+                    check(hipMalloc(reinterpret_cast<void**>(&w_->d_f8_aux), size_t(std::max<int64_t>(aux, 4)) * sizeof(float)), "hipMalloc(f8 aux)");
+                    w_->device_bytes += size_t(aux) * sizeof(float);
+                    w_->act_scale.assign(pi.plan.steps.size(), 0.f);
+                }
             } else if (const char* nf = std::getenv("IE_NO_FRAG_WEIGHTS"); !(nf && std::atoi(nf) != 0)) {
                 for (const Step& st : pi.plan.steps)
                     if (st.kind == StepKind::Conv && st.w_off >= 0 && st.out.c % 16 == 0 && st.in.c % 16 == 0 && st.kh * st.kw <= 49)
@@ -236,11 +254,17 @@ void DeviceModel::BuildInstance(PlanInstance& pi, const std::vector<std::vector<
         }
     }
     std::vector<float>().swap(pi.plan.weights);   // the host copy of the blob is only needed for the first upload
+    AllocInstance(pi);
+}
+
+// Device memory of an instance whose plan is set: activation buffers (element size by buffer type) and split-K scratch.
+void DeviceModel::AllocInstance(PlanInstance& pi) {
     pi.buffers.assign(pi.plan.buffer_floats.size(), nullptr);
     pi.owned.assign(pi.plan.buffer_floats.size(), 0);
     for (size_t i = 0; i < pi.plan.buffer_floats.size(); ++i) {
         float* p = nullptr;
-        size_t bytes = size_t(std::max<int64_t>(pi.plan.buffer_floats[i], 8)) * (pi.plan.buffer_f16[i] ? 2 : 4);
+        const int dt = pi.plan.buffer_f16[i];
+        size_t bytes = size_t(std::max<int64_t>(pi.plan.buffer_floats[i], 16)) * (dt == 2 ? 1 : (dt == 1 ? 2 : 4));
         check(hipMalloc(reinterpret_cast<void**>(&p), bytes), "hipMalloc(activations)");
         check(hipMemsetAsync(p, 0, bytes, stream_), "hipMemset(activations)");
         device_bytes_ += bytes;
@@ -327,11 +351,121 @@ void DeviceModel::WeightsArrived() {
     w_->uploaded = true;
     if (!w_->d_weights16 && !w_->d_weights_frag) return;
     check(hipSetDevice(device_), "hipSetDevice");
+    w_->f8_ready = false;
     if (w_->d_weights16) check(LaunchConvertF32ToF16(w_->d_weights, w_->d_weights16, int64_t(w_->weight_floats), stream_), "convert_f32_f16");
     if (w_->d_weights_frag)
         for (const DeviceWeights::FragRegion& fr : w_->frag_regions)
             check(LaunchPermuteWeightsFrag(w_->d_weights + fr.w_off, w_->d_weights_frag + fr.w_off, fr.cout, fr.kk, fr.cin, stream_), "permute_weights_frag");
     check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+    if (precision_ == Precision::F8) PrepareF8();
+}
+
+namespace {
+
+// The counter-based generator of modelgen/rng.py, so the calibration images have the distribution of
+// modelgen.models.synthetic_input: 0.6 x a coarse per-image grid of random levels (nearest-upsampled) + 0.4 x U[0,1) noise.
+uint64_t rng_mix(uint64_t z) {
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+uint64_t rng_key(uint64_t seed, const std::string& stream) {
+    uint64_t h = 0xCBF29CE484222325ull;
+    for (unsigned char b : stream) { h ^= b; h *= 0x100000001B3ull; }
+    return rng_mix(seed * 0x9E3779B97F4A7C15ull + h);
+}
+float rng_uniform(uint64_t key, uint64_t i) {
+    return float(double(rng_mix(key + (i + 1) * 0x9E3779B97F4A7C15ull) >> 40) * (1.0 / 16777216.0));
+}
+std::vector<float> synthetic_images(int64_t b, int64_t c, int64_t h, int64_t w, const std::string& stream) {
+    std::vector<float> x(size_t(b * c * h * w));
+    const uint64_t kf = rng_key(20250704, stream), kc = rng_key(20250704, stream + "/coarse");
+    if (h < 8 || w < 8) {
+        for (size_t i = 0; i < x.size(); ++i) x[i] = rng_uniform(kf, i);
+        return x;
+    }
+    const int64_t cell = std::max<int64_t>(h / 7, 1), gh = (h + cell - 1) / cell, gw = (w + cell - 1) / cell;
+    for (int64_t n = 0; n < b; ++n)
+        for (int64_t ch = 0; ch < c; ++ch)
+            for (int64_t y = 0; y < h; ++y)
+                for (int64_t xx = 0; xx < w; ++xx) {
+                    const uint64_t i = uint64_t(((n * c + ch) * h + y) * w + xx);
+                    const uint64_t j = uint64_t(((n * c + ch) * gh + y / cell) * gw + xx / cell);
+                    x[i] = 0.6f * rng_uniform(kc, j) + 0.4f * rng_uniform(kf, i);
+                }
+    return x;
+}
+
+}  // namespace
+
+// fp8 mode, once per DeviceWeights (and again after the blob was rewritten):
+//   1. every fp8 conv's weight rows -> e4m3 with a per-row scale (max |w| / 448);
+//   2. calibration: the SAME graph planned in fp16 mode runs eagerly on IE_F8_CALIB_BATCH (default 8) synthetic images and the
+//      max |x| of every step's output is taken; a tensor's scale is margin x max / 448 (margin 2: inputs of another
+//      draw saturate only beyond twice the calibrated range; e4m3 precision is relative, the headroom costs no mantissa bits);
+//      max pools keep their input's scale (their output IS one of their inputs);
+//   3. epilogue multipliers escale[o] = (input tensor scale) x (weight row scale).
+void DeviceModel::PrepareF8() {
+    DeviceWeights& W = *w_;
+    if (W.f8_ready || !W.uploaded) return;
+    check(hipSetDevice(device_), "hipSetDevice");
+    for (const auto& fc : W.f8_convs)
+        check(LaunchQuantizeRowsE4m3(W.d_weights + fc.w_off, static_cast<char*>(W.d_weights8) + fc.w_off, W.d_f8_aux + fc.aux_off, fc.cout, fc.k, stream_),
+              "quantize_rows_e4m3");
+    // ---- calibration pass in fp16 ----
+    int64_t nc = 8;
+    if (const char* e = std::getenv("IE_F8_CALIB_BATCH")) nc = std::max(1, std::min(64, std::atoi(e)));
+    float margin = 2.0f;
+    if (const char* e = std::getenv("IE_F8_MARGIN")) margin = std::max(1.0f, float(std::atof(e)));
+    std::vector<std::vector<int64_t>> shapes;
+    for (const auto& vi : model_->inputs) {
+        std::vector<int64_t> sh = vi.dims;
+        for (size_t k = 0; k < sh.size(); ++k) if (sh[k] <= 0) sh[k] = (k == 0 ? nc : 1);
+        shapes.push_back(sh);
+    }
+    PlanInstance cal;
+    cal.plan = BuildPlan(*model_, shapes, Precision::F16);
+    if (cal.plan.steps.size() != W.act_scale.size()) throw std::runtime_error("fp8 calibration: the fp16 plan of the graph has a different step list");
+    std::vector<float>().swap(cal.plan.weights);
+    float* d_amax = nullptr;
+    try {
+        AllocInstance(cal);
+        check(hipMalloc(reinterpret_cast<void**>(&d_amax), cal.plan.steps.size() * sizeof(float)), "hipMalloc(amax)");
+        check(hipMemsetAsync(d_amax, 0, cal.plan.steps.size() * sizeof(float), stream_), "hipMemset(amax)");
+        for (size_t i = 0; i < cal.plan.inputs.size(); ++i) {
+            const View& v = cal.plan.inputs[i].view;
+            const std::vector<float> x = synthetic_images(v.n, v.c, v.h, v.w, "calibration/" + cal.plan.inputs[i].name);
+            check(hipMemcpyAsync(cal.buffers[size_t(v.buf)], x.data(), x.size() * sizeof(float), hipMemcpyHostToDevice, stream_), "hipMemcpy(calibration input)");
+            check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+        }
+        for (size_t i = 0; i < cal.plan.steps.size(); ++i) {
+            LaunchStep(cal, cal.plan.steps[i], stream_);
+            check(LaunchAbsMax(make_arg(cal, cal.plan.steps[i].out), d_amax + i, stream_), "absmax");
+        }
+        std::vector<float> amax(cal.plan.steps.size());
+        check(hipMemcpyAsync(amax.data(), d_amax, amax.size() * sizeof(float), hipMemcpyDeviceToHost, stream_), "hipMemcpy(amax)");
+        check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+        for (size_t i = 0; i < amax.size(); ++i) {
+            const Step& st = cal.plan.steps[i];
+            float sc = (amax[i] > 0.f ? amax[i] : 1.f) * margin / 448.0f;
+            if (st.kind == StepKind::Pool && st.pool_max && st.in_src >= 0 && W.act_scale[size_t(st.in_src)] > 0.f) sc = W.act_scale[size_t(st.in_src)];
+            W.act_scale[i] = sc;
+        }
+    } catch (...) {
+        if (d_amax) (void)hipFree(d_amax);
+        FreeInstance(cal);
+        throw;
+    }
+    (void)hipFree(d_amax);
+    FreeInstance(cal);
+    for (const auto& fc : W.f8_convs) {
+        if (fc.in_src < 0) throw std::runtime_error("fp8 precision: a conv reads a tensor whose producer is unknown");
+        const int64_t half = (fc.cout + 3) / 4 * 4;
+        check(LaunchScaleVector(W.d_f8_aux + fc.aux_off, W.d_f8_aux + fc.aux_off + half, W.act_scale[size_t(fc.in_src)], fc.cout, stream_), "scale_vector");
+    }
+    check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+    W.f8_ready = true;
 }
 
 // ---- pipelined host path --------------------------------------------------------------------------------------------------
@@ -485,6 +619,43 @@ void DeviceModel::Autotune(PlanInstance& pi, size_t nsteps, bool allow_search) {
                 s.splitk = 1;
             }
             const int64_t M = s.out.n * s.out.h * s.out.w, N = s.out.c;
+            if (s.algo == ConvAlgo::IgemmF8) {
+                // fp8 convs: one kernel family, the search is over its tile shapes
+                std::vector<int64_t> key8 = {M, N, s.in.c, s.kh, s.kw, s.sh, s.sw, s.pt, s.pl, s.in.h, s.in.w, s.in.pitch, s.out.pitch, 0, int64_t(s.algo), 0,
+                                             s.bias_off >= 0, 8, s.has_in2};
+                {
+                    std::lock_guard<std::mutex> g(w_->tune_mu);
+                    auto hit = w_->tune_cache.find(key8);
+                    if (hit != w_->tune_cache.end()) { s.tile = hit->second.first; continue; }
+                }
+                if (!allow_search || !w_->f8_ready) continue;
+                searched = true;
+                float best8 = 1e30f;
+                int best_t = s.tile;
+                for (int t = 0; t < kNumConvF8Tiles; ++t) {
+                    if (kIgemmTiles[t].bn > 32 && N <= 32) continue;
+                    Step trial = s;
+                    trial.tile = t;
+                    LaunchStep(pi, trial, stream_);
+                    float ms_best = 1e30f;
+                    for (int rep = 0; rep < 3; ++rep) {
+                        if (scrub) check(hipMemsetAsync(scrub, 0, kScrubBytes, stream_), "hipMemsetAsync(scrub)");
+                        check(hipEventRecord(e0, stream_), "hipEventRecord");
+                        LaunchStep(pi, trial, stream_);
+                        check(hipEventRecord(e1, stream_), "hipEventRecord");
+                        check(hipEventSynchronize(e1), "hipEventSynchronize");
+                        float ms = 0;
+                        check(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime");
+                        ms_best = std::min(ms_best, ms);
+                    }
+                    if (ms_best < best8) { best8 = ms_best; best_t = t; }
+                }
+                s.tile = best_t;
+                std::lock_guard<std::mutex> g(w_->tune_mu);
+                w_->tune_cache[key8] = {best_t, 1};
+                w_->tune_dirty = true;
+                continue;
+            }
             const int64_t bk = s.in.f16 ? 2 * kIgemmBK : kIgemmBK;
             const int64_t KT = s.algo == ConvAlgo::IgemmVec ? int64_t(s.kh) * s.kw * ((s.in.c + bk - 1) / bk)
                                                            : (int64_t(s.kh) * s.kw * s.in.c + kIgemmBK - 1) / kIgemmBK;
@@ -711,6 +882,17 @@ ConvArgs DeviceModel::MakeConvArgs(const PlanInstance& pi, const Step& s) const 
     a.workspace_floats = pi.workspace_floats;
     a.counters = pi.counters;
     a.num_counters = pi.counters ? kNumCounters : 0;
+    if (s.out.f8 || s.in.f8) {       // fp8 mode: e4m3 weights, per-channel epilogue multipliers, tensor scales
+        const DeviceWeights& W = *w_;
+        auto scale_of = [&](int step) { return step >= 0 && size_t(step) < W.act_scale.size() && W.act_scale[size_t(step)] > 0.f ? W.act_scale[size_t(step)] : 1.f; };
+        a.out_qscale = 1.0f / scale_of(s.idx);
+        a.res_scale = scale_of(s.in2_src);
+        for (const auto& fc : W.f8_convs)
+            if (fc.w_off == s.w_off) {
+                a.w8 = static_cast<const char*>(W.d_weights8) + fc.w_off;
+                a.escale = W.d_f8_aux + fc.aux_off + (fc.cout + 3) / 4 * 4;
+            }
+    }
     return a;
 }
 
@@ -744,6 +926,14 @@ void DeviceModel::LaunchStep(const PlanInstance& pi, const Step& s_in, hipStream
                     sp = &fb;
                 }
             }
+            if (s_in.algo == ConvAlgo::IgemmF8) {
+                // e4m3 tensors: only the fp8 kernel may touch them; a declined launch is an error, never a hand-over to a kernel that
+                // would read the bytes as floats
+                if (!w_->f8_ready) throw std::runtime_error("fp8 precision: scales are not calibrated yet");
+                check(LaunchConvIgemmF8(a, s_in.tile, stream_), "conv_igemm_f8");
+                break;
+            }
+            if (a.in.f8 || a.res.f8 || (a.out.f8 && s_in.algo != ConvAlgo::Stem)) throw std::runtime_error("internal error: fp8 tensor reached a non-fp8 conv kernel");
             const Step& s = *sp;
             // A fused residual Add lives in the weights-stationary 1x1 epilogues; any other kernel runs the conv without its ReLU
             // and adds the shortcut in place afterwards.
@@ -774,14 +964,29 @@ void DeviceModel::LaunchStep(const PlanInstance& pi, const Step& s_in, hipStream
             a.kh = s.kh; a.kw = s.kw; a.sh = s.sh; a.sw = s.sw; a.pt = s.pt; a.pl = s.pl; a.pb = s.pb; a.pr = s.pr;
             a.is_max = s.pool_max; a.count_include_pad = s.count_include_pad;
             a.pre_scale = wp(s.pre_scale_off); a.pre_shift = wp(s.pre_shift_off); a.pre_relu = s.pre_relu;
+            if (a.in.f8 || a.out.f8) {
+                const DeviceWeights& W = *w_;
+                auto scale_of = [&](int step) { return step >= 0 && size_t(step) < W.act_scale.size() && W.act_scale[size_t(step)] > 0.f ? W.act_scale[size_t(step)] : 1.f; };
+                a.in_scale = scale_of(s.in_src);
+                a.out_qscale = 1.0f / scale_of(s.idx);
+                check(LaunchPoolF8(a, stream_), "pool_f8");
+                break;
+            }
             check(LaunchPool(a, stream_), "pool");
             break;
         }
         case StepKind::GlobalAvgPool:
+            if (s.in.f8) {
+                const DeviceWeights& W = *w_;
+                const float sc = s.in_src >= 0 && size_t(s.in_src) < W.act_scale.size() && W.act_scale[size_t(s.in_src)] > 0.f ? W.act_scale[size_t(s.in_src)] : 1.f;
+                check(LaunchGlobalAvgPoolF8(make_arg(pi, s.in), make_arg(pi, s.out), sc, stream_), "global_avg_pool_f8");
+                break;
+            }
             check(LaunchGlobalAvgPool(make_arg(pi, s.in), make_arg(pi, s.out), wp(s.pre_scale_off), wp(s.pre_shift_off),
                                       s.pre_relu, stream_), "global_avg_pool");
             break;
         case StepKind::Eltwise: {
+            if (s.in.f8 || s.out.f8) throw std::runtime_error("internal error: fp8 tensor reached the eltwise kernel");
             EltArgs a;
             a.a = make_arg(pi, s.in);
             if (s.has_in2) a.b = make_arg(pi, s.in2);
@@ -793,6 +998,7 @@ void DeviceModel::LaunchStep(const PlanInstance& pi, const Step& s_in, hipStream
             break;
         }
         case StepKind::Copy:
+            if (s.in.f8 || s.out.f8) throw std::runtime_error("internal error: fp8 tensor reached the copy kernel");
             check(LaunchCopy(make_arg(pi, s.in), make_arg(pi, s.out), stream_), "copy");
             break;
     }
@@ -802,12 +1008,14 @@ static std::string kernel_label(const Step& s) {
     switch (s.kind) {
         case StepKind::Conv:
             if (s.algo == ConvAlgo::Naive) return "conv_naive_kernel";
+            if (s.algo == ConvAlgo::IgemmF8)
+                return "conv_igemm_f8_kernel<" + std::to_string(kIgemmTiles[s.tile].bm) + "x" + std::to_string(kIgemmTiles[s.tile].bn) + ">";
             if (s.algo == ConvAlgo::Direct) {       // one launcher family, three kernels (kernels_direct.hip): report the one that runs
                 const char* k = s.tile >= 10 ? "conv1x1_as_kernel<f32,t" : s.tile >= kNumDirectBaseTiles ? "conv_win_kernel<f32,t"
                                              : s.in.f16 ? "conv_direct_kernel<f16,t" : "conv_direct_kernel<f32,t";
                 return std::string(k) + std::to_string(s.tile) + ">";
             }
-            if (s.algo == ConvAlgo::Stem) return s.out.f16 ? "conv_stem_kernel<f16>" : "conv_stem_kernel<f32>";
+            if (s.algo == ConvAlgo::Stem) return s.out.f8 ? "conv_stem_kernel<f16,e4m3 out>" : (s.out.f16 ? "conv_stem_kernel<f16>" : "conv_stem_kernel<f32>");
             if (s.algo == ConvAlgo::Ws1x1) return std::string(s.in.f16 ? "conv1x1_ws_f16_kernel<t" : "conv1x1_ws_f32_kernel<t") + std::to_string(s.tile) + ">";
             if (s.algo == ConvAlgo::Ws3x3) return "conv3x3_ws_f16_kernel<t" + std::to_string(s.tile) + ">";
             if (s.algo == ConvAlgo::Raster3x3)
@@ -817,8 +1025,8 @@ static std::string kernel_label(const Step& s) {
                    (kIgemmTiles[s.tile].deep ? ",deep" : "") +
                    (s.algo == ConvAlgo::IgemmVec ? ",vec" : ",scalar") +
                    (s.splitk > 1 ? ",splitk" + std::to_string(s.splitk) : std::string()) + ">";
-        case StepKind::Pool: return "pool_kernel";
-        case StepKind::GlobalAvgPool: return "gap_kernel";
+        case StepKind::Pool: return s.in.f8 ? "pool_f8_kernel" : "pool_kernel";
+        case StepKind::GlobalAvgPool: return s.in.f8 ? "gap_f8_kernel" : "gap_kernel";
         case StepKind::Eltwise: return "eltwise_kernel";
         case StepKind::Copy: return "copy_kernel";
     }

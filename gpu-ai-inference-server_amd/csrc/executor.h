@@ -35,6 +35,14 @@ struct DeviceWeights {
     void* d_weights16 = nullptr;       // fp16 / fp8 modes: the same blob as halfs, same element offsets
     float* d_weights_frag = nullptr;   // fp32 mode: conv weights again in MFMA-fragment order at the same offsets
     void* d_weights8 = nullptr;        // fp8 mode: conv weights as OCP e4m3 bytes at the same element offsets (per-output-channel scaled)
+    // fp8 mode: per fp8 conv (keyed by its weight offset) 2 x Cout floats in d_f8_aux: the weight rows' scales, then the epilogue
+    // multipliers escale[o] = (input tensor scale) x (weight row scale); act_scale[i] = scale of the tensor step i writes (real = q x
+    // scale), found by a calibration pass at load
+    float* d_f8_aux = nullptr;
+    struct F8Conv { int step; int64_t w_off; int cout, k; int in_src; int64_t aux_off; };
+    std::vector<F8Conv> f8_convs;
+    std::vector<float> act_scale;
+    bool f8_ready = false;
     struct FragRegion { int64_t w_off; int cout, kk, cin; };
     std::vector<FragRegion> frag_regions;
     size_t weight_floats = 0;
@@ -136,6 +144,8 @@ private:
     void Autotune(PlanInstance& pi, size_t nsteps, bool allow_search);
     void SaveTuneCache();
     void EnsurePipeline(PlanInstance& pi, bool allow_tune);
+    void AllocInstance(PlanInstance& pi);
+    void PrepareF8();       // quantise the conv weights, calibrate the activation scales, derive the epilogue multipliers (once per DeviceWeights)
     void LaunchStep(const PlanInstance& pi, const Step& s, hipStream_t stream);
     ConvArgs MakeConvArgs(const PlanInstance& pi, const Step& s) const;
 

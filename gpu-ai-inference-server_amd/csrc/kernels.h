@@ -16,6 +16,7 @@ struct TensorArg {
     int n = 0, h = 0, w = 0, c = 0;
     int64_t sn = 0, sh = 0, sw = 0, sc = 0;
     int f16 = 0;
+    int f8 = 0;                        // the buffer holds OCP e4m3 bytes (fp8 precision mode); strides in ELEMENTS = bytes; never set together with f16
 };
 
 struct ConvArgs {
@@ -35,6 +36,11 @@ struct ConvArgs {
     int64_t workspace_floats = 0;      // capacity of `workspace`
     int* counters = nullptr;           // per-tile arrival counters for the in-launch combine; null = two-pass reduce kernel
     int num_counters = 0;
+    // fp8 precision mode (kernels_f8.hip): e4m3 weights at the same element offsets as `w`, the per-output-channel multiplier that
+    // turns the e4m3 x e4m3 dot product into real units (input scale x weight-row scale), the shortcut's scale, 1 / output scale
+    const void* w8 = nullptr;
+    const float* escale = nullptr;
+    float res_scale = 1.f, out_qscale = 1.f;
     int debug = 0;                     // timing-only ablation bits (IE_DEBUG_ABLATE), 0 in production
     int64_t in_bytes = 0;              // filled by LaunchConvIgemm: byte span of the input view (buffer descriptor range)
 };
@@ -46,6 +52,7 @@ struct PoolArgs {
     const float* pre_scale = nullptr;  // per channel: x <- x*scale + shift (then ReLU if pre_relu) before pooling
     const float* pre_shift = nullptr;  // (a transition's BN -> ReLU -> 1x1 conv -> AvgPool runs as BN -> ReLU -> AvgPool -> 1x1 conv)
     int pre_relu = 0;
+    float in_scale = 1.f, out_qscale = 1.f;   // e4m3 tensors: real = q * in_scale, q_out = real * out_qscale
 };
 
 struct EltArgs {
@@ -105,6 +112,20 @@ hipError_t InitKernelsDirect();
 bool ConvStemEligible(const ConvArgs& a);
 hipError_t LaunchConvStem(const ConvArgs& a, hipStream_t stream);
 hipError_t InitKernelsStem();
+// fp8 precision mode (kernels_f8.hip): implicit GEMM on v_mfma_f32_32x32x16_fp8_fp8 over e4m3 NHWC activations and e4m3 weights,
+// fp32 accumulate, per-channel rescale + bias + e4m3 shortcut + ReLU + re-quantisation in the epilogue.  Tiles 0..6 of kIgemmTiles.
+constexpr int kNumConvF8Tiles = 7;
+bool ConvF8Eligible(const ConvArgs& a, int tile);
+hipError_t LaunchConvIgemmF8(const ConvArgs& a, int tile, hipStream_t stream);
+hipError_t InitKernelsF8();
+// w8[o, :] = e4m3(w[o, :] / wscale[o]) with wscale[o] = max|w[o, :]| / 448, one workgroup per row
+hipError_t LaunchQuantizeRowsE4m3(const float* w, void* w8, float* wscale, int rows, int K, hipStream_t stream);
+hipError_t LaunchScaleVector(const float* src, float* dst, float s, int n, hipStream_t stream);
+hipError_t LaunchPoolF8(const PoolArgs& a, hipStream_t stream);
+hipError_t LaunchGlobalAvgPoolF8(const TensorArg& in, const TensorArg& out, float in_scale, hipStream_t stream);
+// calibration: *result = max(*result, max |x| over the view) (fp32 / half views; *result must start at 0)
+hipError_t LaunchAbsMax(const TensorArg& t, float* result, hipStream_t stream);
+hipError_t LaunchE4m3RoundTrip(const float* src, float* dst, void* codes, float scale, int64_t n, hipStream_t stream);
 hipError_t LaunchConvertF32ToF16(const float* src, void* dst, int64_t n, hipStream_t stream);
 // UINT8 ingest: dst[i] = float(src[i]) * scale + bias (images travel over PCIe as bytes, 4x fewer than fp32)
 hipError_t LaunchConvertU8ToF32(const void* src, float* dst, int64_t n, float scale, float bias, hipStream_t stream);

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_stem_kernel(const ConvArgs a,
     for (int q = tid; q < 64; q += NT) sBias[q] = (a.bias != nullptr && q < Cout) ? a.bias[q] : 0.f;
 
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(a.in.p, 0, int(a.in_bytes), 0x00020000);
-    const int esz = a.out.f16 ? 2 : 4;
+    const int esz = a.out.f8 ? 1 : (a.out.f16 ? 2 : 4);
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
         a.out.p, 0, int((int64_t(a.out.n) * OH * OW - 1) * opitch * esz + Cout * esz), 0x00020000);
 
@@ -163,7 +163,24 @@ __global__ __launch_bounds__(64 * WAVES) void conv_stem_kernel(const ConvArgs a,
                     acc[j][4 * gq + q] = 0.f;
                 }
             }
-            if (a.out.f16) {
+            if (a.out.f8) {
+                // fp8 mode: re-quantise with 1 / (output scale), one dword of four e4m3 per quad, then the half-waves trade quads so
+                // each lane stores 16 consecutive channels (same exchange as conv_igemm_f8_kernel)
+                unsigned d[4];
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    float q4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) q4[q] = __builtin_fminf(__builtin_fmaxf(v[4 * gq + q] * a.out_qscale, -448.f), 448.f);
+                    int pk = __builtin_amdgcn_cvt_pk_fp8_f32(q4[0], q4[1], 0, false);
+                    pk = __builtin_amdgcn_cvt_pk_fp8_f32(q4[2], q4[3], pk, true);
+                    d[gq] = unsigned(pk);
+                }
+                const auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
+                const int n = j * 32 + 16 * hh;
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s0[1], s1[0], s1[1]}, rs_out, n < Cout ? rowoff + unsigned(n) : OOB, 0, 0);
+            } else if (a.out.f16) {
 #pragma unroll
                 for (int gp = 0; gp < 2; ++gp) {
                     const h4 qa = {_Float16(v[8 * gp + 0]), _Float16(v[8 * gp + 1]), _Float16(v[8 * gp + 2]), _Float16(v[8 * gp + 3])};
@@ -222,6 +239,7 @@ bool ConvStemEligible(const ConvArgs& a) {
     if (a.pre_scale != nullptr || a.w == nullptr) return false;
     if (a.in.sw != 1 || a.in.sh != a.in.w || a.in.sc != int64_t(a.in.h) * a.in.w || a.in.sn != a.in.sc * a.in.c) return false;   // dense NCHW
     if (a.out.sc != 1 || a.out.c > 64 || (a.out.c & 7) || (a.out.sw & 7) || (reinterpret_cast<uintptr_t>(a.out.p) & 15)) return false;
+    if (a.out.f8 && ((a.out.c & 15) || (a.out.sw & 15))) return false;
     if (a.out.sh != a.out.w * a.out.sw || a.out.sn != a.out.h * a.out.sh) return false;
     if (a.out.h != (a.in.h + 6 - 7) / 2 + 1 || a.out.w != (a.in.w + 6 - 7) / 2 + 1) return false;
     const int64_t in_elems = int64_t(a.in.n) * 3 * a.in.h * a.in.w, out_elems = int64_t(a.out.n) * a.out.h * a.out.w * a.out.sw;
@@ -257,7 +275,7 @@ hipError_t LaunchConvStem(const ConvArgs& a_in, hipStream_t stream) {
     ConvArgs a = a_in;
     a.in_bytes = int64_t(a.in.n) * a.in.c * a.in.h * a.in.w * 4;
     // half arithmetic only when the result is stored as half anyway (fp16 precision mode)
-    return a.out.f16 ? launch_stem_t<_Float16>(a, stream) : launch_stem_t<float>(a, stream);
+    return (a.out.f16 || a.out.f8) ? launch_stem_t<_Float16>(a, stream) : launch_stem_t<float>(a, stream);
 }
 
 hipError_t InitKernelsStem() {

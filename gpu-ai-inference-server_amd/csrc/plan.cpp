@@ -26,6 +26,7 @@ struct Val {
     int root = -1;
     int64_t abs_off = 0;
     int buf = -1;
+    bool dedicated = false;             // its buffer is never recycled
 };
 
 enum LKind { L_CONV, L_AFFINE, L_RELU, L_ADD, L_CONCAT, L_MAXPOOL, L_AVGPOOL, L_GAP, L_ALIAS, L_COPY };
@@ -759,7 +760,10 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
     std::multimap<int64_t, int> free_pool;   // size -> buffer id
     auto alloc_buf = [&](int r) {
         int64_t need = root_floats(r);
-        bool dedicated = last_use[r] == INF;
+        // fp8 mode types buffers by tensor shape ([N, C] vectors are halfs, spatial tensors e4m3): vectors get their own buffers so
+        // a recycled buffer never changes element type
+        bool dedicated = last_use[r] == INF || (precision == Precision::F8 && L.vals[r].h * L.vals[r].w == 1);
+        L.vals[r].dedicated = dedicated;
         if (!dedicated) {
             auto it = free_pool.lower_bound(need);
             // accept a recycled buffer up to 2x the needed size; otherwise grow a new one
@@ -779,13 +783,16 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
         for (size_t v = 0; v < L.vals.size(); ++v)
             if (used[v] && L.vals[v].root == int(v) && first_def[v] == int(pos)) alloc_buf(int(v));
         for (size_t v = 0; v < L.vals.size(); ++v)
-            if (used[v] && L.vals[v].root == int(v) && last_use[v] == int(pos) && L.vals[v].buf >= 0)
+            if (used[v] && L.vals[v].root == int(v) && last_use[v] == int(pos) && L.vals[v].buf >= 0 && !L.vals[v].dedicated)
                 free_pool.insert({plan.buffer_floats[size_t(L.vals[v].buf)], L.vals[v].buf});
     }
 
     // fp16 mode: every buffer except the graph's own inputs/outputs (dedicated, never recycled) holds halfs
     auto mark_buffer_types = [&] {
-        plan.buffer_f16.assign(plan.buffer_floats.size(), precision == Precision::F16 ? 1 : 0);
+        plan.buffer_f16.assign(plan.buffer_floats.size(), precision == Precision::F16 ? 1 : (precision == Precision::F8 ? 2 : 0));
+        if (precision == Precision::F8)
+            for (size_t v = 0; v < L.vals.size(); ++v)
+                if (used[v] && L.vals[v].root == int(v) && L.vals[v].buf >= 0 && L.vals[v].h * L.vals[v].w == 1) plan.buffer_f16[size_t(L.vals[v].buf)] = 1;
         for (size_t v = 0; v < L.vals.size(); ++v)
             if (L.vals[v].is_input && L.vals[L.vals[v].root].buf >= 0) plan.buffer_f16[size_t(L.vals[L.vals[v].root].buf)] = 0;
         for (int v : out_vals)
@@ -798,7 +805,8 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
         const Val& R = L.vals[X.root];
         View w;
         w.buf = R.buf;
-        w.f16 = R.buf >= 0 && plan.buffer_f16[size_t(R.buf)] != 0;
+        w.f16 = R.buf >= 0 && plan.buffer_f16[size_t(R.buf)] == 1;
+        w.f8 = R.buf >= 0 && plan.buffer_f16[size_t(R.buf)] == 2;
         w.n = X.n; w.c = X.c; w.h = X.h; w.w = X.w;
         w.c_off = X.abs_off;
         w.pitch = R.c;
@@ -814,7 +822,13 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
         plan.weights.insert(plan.weights.end(), v.begin(), v.end());
         return off;
     };
-    auto vbytes = [](const View& v) { return double(v.numel()) * (v.f16 ? 2.0 : 4.0); };
+    auto vbytes = [](const View& v) { return double(v.numel()) * double(v.esize()); };
+    // who wrote what: (buffer, channel offset, channels) -> step index, for Step::in_src / in2_src
+    std::map<std::vector<int64_t>, int> writer;
+    auto src_of = [&](const View& v) {
+        auto it = writer.find({int64_t(v.buf), v.c_off, v.c});
+        return it == writer.end() ? -1 : it->second;
+    };
     for (int idx : order) {
         const LNode& n = L.nodes[idx];
         if (n.kind == L_ALIAS) continue;
@@ -835,6 +849,10 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                     c.out.c = src.c;
                     c.out.c_off += off;
                     c.bytes = vbytes(c.in) + vbytes(c.out);
+                    if (c.in.f8 || c.out.f8) fail("fp8 precision: concat copy " + c.name + " of an fp8 tensor is not supported");
+                    c.idx = int(plan.steps.size());
+                    c.in_src = src_of(c.in);
+                    writer[{int64_t(c.out.buf), c.out.c_off, c.out.c}] = c.idx;
                     plan.steps.push_back(c);
                 }
                 off += src.c;
@@ -859,8 +877,9 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                 int64_t M = s.out.n * s.out.h * s.out.w, N = s.out.c, K = int64_t(n.kh) * n.kw * s.in.c;
                 s.flops = 2.0 * double(M) * double(N) * double(K);
                 const bool in16 = s.in.f16;
-                s.bytes = vbytes(s.in) + vbytes(s.out) + (in16 ? 2.0 : 4.0) * double(n.w.size()) + (n.res >= 0 ? vbytes(s.in2) : 0.0);
-                bool vec_ok = !in16 && !s.in.nchw && s.in.c % 4 == 0 && s.in.pitch % 4 == 0 && s.in.c_off % 4 == 0 && n.kh * n.kw <= 32 &&
+                const bool in8 = s.in.f8;
+                s.bytes = vbytes(s.in) + vbytes(s.out) + (in8 ? 1.0 : (in16 ? 2.0 : 4.0)) * double(n.w.size()) + (n.res >= 0 ? vbytes(s.in2) : 0.0);
+                bool vec_ok = !in16 && !in8 && !s.in.nchw && s.in.c % 4 == 0 && s.in.pitch % 4 == 0 && s.in.c_off % 4 == 0 && n.kh * n.kw <= 32 &&
                               s.in.n * s.in.h * s.in.w * s.in.pitch * 4 < (int64_t(1) << 31) && int64_t(n.w.size()) * 4 < (int64_t(1) << 31);
                 // fp16 MFMA path: 16-byte chunks of 8 halfs, so channel counts / slice offsets must be multiples of 8
                 const bool vec16_ok = in16 && !s.in.nchw && s.in.c % 8 == 0 && s.in.pitch % 8 == 0 && s.in.c_off % 8 == 0 && n.kh * n.kw <= 32 &&
@@ -878,7 +897,22 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                                      n.pl == 3 && n.pb == 3 && n.pr == 3 && !n.has_pre && N <= 64 && N % 8 == 0 && s.out.pitch % 8 == 0 &&
                                      s.out.c_off % 8 == 0 && s.in.numel() * 4 < (int64_t(1) << 31) &&
                                      s.out.n * s.out.h * s.out.w * s.out.pitch * 4 < (int64_t(1) << 31);
-                if (stem_ok && M * N >= 2048) s.algo = ConvAlgo::Stem;
+                if (stem_ok && M * N >= 2048 && !(s.out.f8 && (N % 16 || s.out.pitch % 16 || s.out.c_off % 16))) s.algo = ConvAlgo::Stem;
+                if (in8 || s.out.f8) {
+                    // fp8 mode: e4m3 tensors are only understood by the fp8 kernels; anything they cannot run is a load error, never a
+                    // silent reinterpretation of the bytes by another kernel
+                    if (s.out.f8 && !in8) {
+                        if (s.algo != ConvAlgo::Stem)
+                            fail("fp8 precision: conv " + n.name + " reads a non-fp8 tensor and writes an fp8 one; only the 7x7/s2 stem over the fp32 graph input does that");
+                    } else {
+                        if (n.has_pre) fail("fp8 precision: conv " + n.name + " has an activation prologue (pre-activation graphs are not supported in fp8 mode)");
+                        if (!s.out.f8) fail("fp8 precision: conv " + n.name + " reads an fp8 tensor and writes a non-fp8 one");
+                        if (s.in.nchw || s.in.c % 16 || s.in.pitch % 16 || s.in.c_off % 16 || N % 16 || s.out.pitch % 16 || s.out.c_off % 16 || n.kh * n.kw > 32)
+                            fail("fp8 precision: conv " + n.name + " needs channel counts and slice offsets that are multiples of 16");
+                        if (n.res >= 0 && !s.in2.f8) fail("fp8 precision: the shortcut of conv " + n.name + " is not an fp8 tensor");
+                        s.algo = ConvAlgo::IgemmF8;
+                    }
+                }
                 s.tile = choose_tile(M, N);
                 s.splitk = 1;
                 const int heuristic_tile = s.tile;
@@ -933,6 +967,10 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                 const bool raster_ok = vec_ok && !s.out.f16 && is3x3 && !n.has_pre;
                 // ---- default choice without the autotuner (IE_AUTOTUNE=0, or before Prepare() has timed anything): the kernels
                 //      the exhaustive search picks for DenseNet / ResNet shapes ----
+                if (s.algo == ConvAlgo::IgemmF8) {
+                    if (const char* ft = std::getenv("IE_FORCE_TILE")) { int t = std::atoi(ft); if (t >= 0 && t < kNumIgemmBaseTiles && !(kIgemmTiles[t].bn > 32 && N <= 32)) s.tile = t; }
+                    break;
+                }
                 if (!std::getenv("IE_FORCE_ALGO") && !std::getenv("IE_FORCE_TILE") && s.algo == ConvAlgo::IgemmVec) {
                     int pick = -1;
                     if (M <= 2048) {                                                       // tiny grids: split K over the waves
@@ -1015,6 +1053,8 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                 break;
             }
             case L_MAXPOOL: case L_AVGPOOL:
+                if ((s.in.f8 || s.out.f8) && (!s.in.f8 || !s.out.f8 || n.has_pre || s.in.c % 16 || s.in.pitch % 16 || s.in.c_off % 16 || s.out.pitch % 16 || s.out.c_off % 16))
+                    fail("fp8 precision: pool " + n.name + " needs fp8 operands without a prologue and channel counts that are multiples of 16");
                 s.kind = StepKind::Pool;
                 s.pool_max = n.kind == L_MAXPOOL;
                 s.count_include_pad = n.count_include_pad;
@@ -1023,11 +1063,13 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                 s.flops = double(s.out.numel()) * n.kh * n.kw;
                 break;
             case L_GAP:
+                if (s.in.f8 && (n.has_pre || s.out.f8)) fail("fp8 precision: global pool " + n.name + " with a prologue is not supported");
                 s.kind = StepKind::GlobalAvgPool;
                 s.bytes = vbytes(s.in) + vbytes(s.out);
                 s.flops = double(s.in.numel());
                 break;
             case L_AFFINE:
+                if (s.in.f8 || s.out.f8) fail("fp8 precision: stand-alone scale/shift " + n.name + " on an fp8 tensor is not supported");
                 s.kind = StepKind::Eltwise;
                 s.pre_scale_off = push_vec(n.s);
                 s.pre_shift_off = push_vec(n.t);
@@ -1035,11 +1077,13 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                 s.flops = 2.0 * double(s.in.numel());
                 break;
             case L_RELU:
+                if (s.in.f8 || s.out.f8) fail("fp8 precision: stand-alone Relu " + n.name + " on an fp8 tensor is not supported");
                 s.kind = StepKind::Eltwise;
                 s.relu = true;
                 s.bytes = vbytes(s.in) + vbytes(s.out);
                 break;
             case L_ADD:
+                if (s.in.f8 || s.out.f8) fail("fp8 precision: stand-alone Add " + n.name + " on fp8 tensors is not supported (only shortcuts folded into a conv)");
                 s.kind = StepKind::Eltwise;
                 s.in2 = view_of(n.in[1]);
                 s.has_in2 = true;
@@ -1047,6 +1091,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                 s.flops = double(s.in.numel());
                 break;
             case L_COPY:
+                if (s.in.f8 || s.out.f8) fail("fp8 precision: layout copy " + n.name + " of an fp8 tensor is not supported");
                 s.kind = StepKind::Copy;
                 s.bytes = vbytes(s.in) + vbytes(s.out);
                 break;
@@ -1054,6 +1099,10 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
         }
         if (s.kind != StepKind::Conv && s.kind != StepKind::Copy && s.in.nchw)
             fail("internal planner error: NCHW view reached a non-conv step");
+        s.idx = int(plan.steps.size());
+        s.in_src = src_of(s.in);
+        if (s.has_in2) s.in2_src = src_of(s.in2);
+        writer[{int64_t(s.out.buf), s.out.c_off, s.out.c}] = int(plan.steps.size());
         plan.total_flops += s.flops;
         plan.total_bytes += s.bytes;
         plan.steps.push_back(std::move(s));
@@ -1093,7 +1142,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
 static void json_view(std::ostringstream& o, const View& v) {
     o << "{\"buf\":" << v.buf << ",\"n\":" << v.n << ",\"c\":" << v.c << ",\"h\":" << v.h << ",\"w\":" << v.w
       << ",\"c_off\":" << v.c_off << ",\"pitch\":" << v.pitch << ",\"nchw\":" << (v.nchw ? "true" : "false")
-      << ",\"f16\":" << (v.f16 ? "true" : "false") << "}";
+      << ",\"f16\":" << (v.f16 ? "true" : "false") << ",\"f8\":" << (v.f8 ? "true" : "false") << "}";
 }
 static std::string json_escape(const std::string& s) {
     std::string o;
@@ -1103,7 +1152,7 @@ static std::string json_escape(const std::string& s) {
 
 std::string PlanToJson(const Plan& p) {
     static const char* kinds[] = {"conv", "pool", "gap", "eltwise", "copy"};
-    static const char* algos[] = {"igemm_vec", "igemm_scalar", "naive", "raster3x3", "ws1x1", "ws3x3", "stem", "direct"};
+    static const char* algos[] = {"igemm_vec", "igemm_scalar", "naive", "raster3x3", "ws1x1", "ws3x3", "stem", "direct", "igemm_f8"};
     std::ostringstream o;
     o.precision(17);
     o << "{\"inputs\":[";
@@ -1120,7 +1169,7 @@ std::string PlanToJson(const Plan& p) {
     }
     o << "],\"buffers\":[";
     for (size_t i = 0; i < p.buffer_floats.size(); ++i) o << (i ? "," : "") << p.buffer_floats[i];
-    o << "],\"precision\":\"" << (p.precision == Precision::F16 ? "fp16" : "fp32") << "\",\"activation_bytes\":" << p.activation_bytes()
+    o << "],\"precision\":\"" << (p.precision == Precision::F16 ? "fp16" : (p.precision == Precision::F8 ? "fp8" : "fp32")) << "\",\"activation_bytes\":" << p.activation_bytes()
       << ",\"workspace_floats\":" << p.workspace_floats << ",\"weight_floats\":" << p.weights.size() << ",\"total_flops\":" << p.total_flops
       << ",\"total_bytes\":" << p.total_bytes << ",\"steps\":[";
     for (size_t i = 0; i < p.steps.size(); ++i) {
@@ -1136,6 +1185,8 @@ std::string PlanToJson(const Plan& p) {
           << ",\"relu\":" << (s.relu ? "true" : "false") << ",\"bias\":" << (s.bias_off >= 0 ? "true" : "false");
         if (s.kind == StepKind::Conv) o << ",\"algo\":\"" << algos[int(s.algo)] << "\",\"tile\":" << s.tile << ",\"splitk\":" << s.splitk;
         if (s.kind == StepKind::Pool) o << ",\"max\":" << (s.pool_max ? "true" : "false");
+        o << ",\"idx\":" << s.idx << ",\"in_src\":" << s.in_src << ",\"in2_src\":" << s.in2_src << ",\"w_off\":" << s.w_off << ",\"bias_off\":" << s.bias_off
+          << ",\"pre_scale_off\":" << s.pre_scale_off << ",\"pre_shift_off\":" << s.pre_shift_off << ",\"count_include_pad\":" << (s.count_include_pad ? "true" : "false");
         o << ",\"flops\":" << s.flops << ",\"bytes\":" << s.bytes << "}";
     }
     o << "]}";

@@ -25,13 +25,18 @@ struct View {
     int64_t pitch = 0;    // floats per pixel row of the buffer (>= c_off + c)
     bool nchw = false;    // dense NCHW (pitch/c_off unused)
     bool f16 = false;     // elements are IEEE halfs (fp16 precision mode: every buffer that is not a graph input/output)
+    bool f8 = false;      // elements are OCP e4m3 bytes with one per-tensor scale (fp8 precision mode: spatial tensors between stem and global pool)
     int64_t numel() const { return n * c * h * w; }
+    int esize() const { return f8 ? 1 : (f16 ? 2 : 4); }
 };
 
 // Storage/compute precision of a plan.  F16: activations between the graph's fp32 inputs and outputs are stored as halfs and
 // the convolutions run on the fp16 MFMA path with fp32 accumulation (BASELINE.json configs[2-3]); folded BN scale/shift,
 // biases and split-K partial sums stay fp32.
-enum class Precision : int { F32 = 0, F16 = 1 };
+// F8 (BASELINE.json configs[4]): spatial activations are stored as OCP e4m3 with a per-tensor scale calibrated at load, conv weights
+// as e4m3 with a per-output-channel scale, the convolutions run on the fp8 MFMA path with fp32 accumulation; [N, C] vectors (after
+// the global pool) are halfs, graph inputs / outputs stay fp32.
+enum class Precision : int { F32 = 0, F16 = 1, F8 = 2 };
 
 enum class StepKind : int { Conv = 0, Pool = 1, GlobalAvgPool = 2, Eltwise = 3, Copy = 4 };
 
@@ -44,7 +49,8 @@ enum class ConvAlgo : int {
     Ws1x1 = 4,        // weights-stationary 1x1/s1 conv (fp32 and fp16), activations streamed from HBM into MFMA fragments
     Ws3x3 = 5,        // fp16 mode: weights-stationary 3x3/s1/p1 conv (Cout <= 32), raster window in LDS
     Stem = 6,         // 7x7/s2/p3 conv over the 3-channel NCHW fp32 graph input: LDS window per output tile, weights resident
-    Direct = 7        // small output grids: K split over the waves of a workgroup, operands loaded straight into MFMA fragments
+    Direct = 7,       // small output grids: K split over the waves of a workgroup, operands loaded straight into MFMA fragments
+    IgemmF8 = 8       // fp8 mode: implicit GEMM over e4m3 activations / weights (v_mfma_f32_32x32x16_fp8_fp8)
 };
 
 struct Step {
@@ -66,6 +72,8 @@ struct Step {
     int tile = 0;              // igemm tile configuration index (see igemm_tiles.h)
     int base_tile = 0;         // the tiled implicit GEMM's heuristic tile (what the executor falls back to when a specialised launcher declines)
     int splitk = 1;            // >1: K-tiles split over this many workgroups per output tile (+ reduce kernel)
+    int idx = -1;              // position in Plan::steps
+    int in_src = -1, in2_src = -1;   // index of the step that produced `in` / `in2` (-1: a graph input); fp8 mode looks the tensors' scales up by it
     double flops = 0;          // algorithmic FLOPs (2*MACs) of this step for the planned shape
     double bytes = 0;          // algorithmic bytes: operands read once + result written once
 };
@@ -82,7 +90,7 @@ struct Plan {
     std::vector<IoDesc> inputs, outputs;
     Precision precision = Precision::F32;
     std::vector<int64_t> buffer_floats;   // size of each device activation buffer in ELEMENTS
-    std::vector<char> buffer_f16;         // element type of each buffer (1 = half)
+    std::vector<char> buffer_f16;         // element type of each buffer: 0 = float, 1 = half, 2 = e4m3 byte
     std::vector<Step> steps;
     std::vector<float> weights;           // packed blob (batch independent)
     int64_t workspace_floats = 0;         // split-K partial-sum slabs (max over steps of splitk*M*Cout)
@@ -90,7 +98,7 @@ struct Plan {
     int64_t activation_floats() const { int64_t s = 0; for (auto b : buffer_floats) s += b; return s; }
     int64_t activation_bytes() const {
         int64_t s = 0;
-        for (size_t i = 0; i < buffer_floats.size(); ++i) s += buffer_floats[i] * (buffer_f16[i] ? 2 : 4);
+        for (size_t i = 0; i < buffer_floats.size(); ++i) s += buffer_floats[i] * (buffer_f16[i] == 2 ? 1 : (buffer_f16[i] ? 2 : 4));
         return s;
     }
 };

@@ -19,6 +19,11 @@ extern "C" {
  * execution plan for that batch (symbolic leading dims are replaced by `batch`).  NULL + *error on failure. */
 char* EngineDescribeModel(const char* path, int batch, ErrorMessage* error);
 
+/* Host-only: the packed fp32 weight blob of the plan (folded BatchNorm scale/shift vectors, biases, conv weights repacked
+ * [Cout][kh][kw][Cin]) whose element offsets EngineDescribeModel's plan steps carry (w_off, bias_off, pre_scale_off, pre_shift_off).
+ * The blob is batch independent and identical for every precision mode.  malloc'd, release with FreeErrorMessage(). */
+float* EnginePlanWeights(const char* path, int batch, size_t* count, ErrorMessage* error);
+
 /* Plan + allocate + capture the hipGraph for these input shapes (one Shape per graph input, graph order) and return
  * the engine-owned device buffers: d_inputs[i] is dense NCHW fp32 of input i, d_outputs[j] dense fp32 of output j. */
 bool EnginePrepare(ModelHandle handle, const Shape* input_shapes, int num_inputs, void** d_inputs, void** d_outputs,
@@ -37,7 +42,7 @@ bool EngineGetWeightBlob(ModelHandle handle, void** d_ptr, size_t* bytes, ErrorM
 /* Tell the engine the fp32 blob was rewritten in place (e.g. by an RCCL broadcast): in fp16 precision mode the half
  * mirror the MFMA path reads is re-derived from it.  No-op in fp32 mode. */
 bool EngineWeightsUpdated(ModelHandle handle, ErrorMessage* error);
-/* 0 = fp32, 1 = fp16 (IE_PRECISION or config.json "precision"), -1 = model not loaded. */
+/* 0 = fp32, 1 = fp16, 2 = fp8 (IE_PRECISION or config.json "precision"), -1 = model not loaded. */
 int EngineGetPrecision(ModelHandle handle);
 /* Synchronous hipMemcpy on the model's device: kind 1 = host->device, 2 = device->host, 3 = device->device.
  * Lets a test or benchmark fill / read the engine-owned buffers returned by EnginePrepare. */
@@ -60,6 +65,9 @@ bool EngineGetShardStats(ModelHandle handle, int* num_shards, int64_t* sharded_c
  * packed weight blob as it sits in HBM (waits for in-flight requests).  The one-line form of the same facts is what
  * ModelGetMetadata() returns in `description`.  malloc'd, release with FreeErrorMessage(). */
 char* EngineGetRuntimeInfo(ModelHandle handle, int with_checksums, ErrorMessage* error);
+/* The device's OCP e4m3 conversion as the fp8 kernels use it: codes[i] = e4m3(src[i] / scale) (round to nearest even, saturating at
+ * +-448), dst[i] = decode(codes[i]) * scale.  `codes` may be NULL.  Test support for the fp8 precision mode. */
+bool EngineE4m3RoundTrip(const float* src, float* dst, unsigned char* codes, size_t n, float scale, ErrorMessage* error);
 /* result = a + b on the GPU for host arrays (the reference's VectorAdd smoke test, cuda_utils.cu:59-149). */
 bool EngineVectorAdd(const float* a, const float* b, float* result, size_t n, ErrorMessage* error);
 

@@ -217,3 +217,62 @@ def test_two_input_graph_plan(tmp_path):
     d = B.DescribeModel(path, 4)
     assert [i["name"] for i in d["inputs"]] == ["b_in", "a_in"]            # graph order, not alphabetical
     assert [i["dims"] for i in d["plan"]["inputs"]] == [[4, 16, 12, 12], [4, 8, 12, 12]]
+
+
+def test_plan_interpreter_reproduces_the_onnx_oracle(tmp_path):
+    """oracle/fp8.py run_plan executes the FUSED plan (EngineDescribeModel's step list + the packed weight blob, both host-only) in
+    float64.  Agreement with the ONNX-operator oracle proves the planner's rewrites on the CPU: BN folding into weights / prologues,
+    Scale merging, residual absorption, the AvgPool <-> 1x1 swap, concat-by-placement, buffer recycling."""
+    from conftest import MINI
+    from oracle import fp8 as F
+    for name, (mk, iname, ishape) in MINI.items():
+        mb = mk(models)
+        path = models.write_repo(str(tmp_path), name, mb)
+        plan = B.DescribeModel(path, ishape[0])["plan"]
+        blob = B.PlanWeights(path, ishape[0])
+        assert blob.size == plan["weight_floats"]
+        x = models.synthetic_input(ishape, stream=name)
+        (ref,) = O.run(O.load_model(mb), {iname: x}, dtype=np.float64).values()
+        (y,) = F.run_plan(plan, blob, {iname: x}).values()
+        assert y.shape == ref.shape
+        assert np.abs(y - ref).max() / np.abs(ref).max() < 5e-7, name
+
+
+def test_e4m3_emulation_follows_the_ofp8_format():
+    from oracle import fp8 as F
+    v = F.e4m3_decode(np.arange(256, dtype=np.uint8))
+    assert v[0x7E] == 448 and v[0xFE] == -448 and np.isnan(v[0x7F]) and np.isnan(v[0xFF])          # no infinities, one NaN per sign
+    assert v[0x01] == 2.0 ** -9 and v[0x08] == 2.0 ** -6 and v[0x38] == 1.0                         # smallest subnormal, smallest normal, one
+    fin = ~np.isnan(v)
+    back = F.e4m3_encode(v[fin])
+    assert np.array_equal(back[1:127], np.arange(1, 127, dtype=np.uint8)) and np.array_equal(F.e4m3_decode(back), v[fin])
+    # round to nearest, ties to even mantissa; saturation instead of overflow
+    assert F.e4m3_decode(F.e4m3_encode(np.array([17.0, 19.0, 21.0, 1.5 * 2 ** -9, 2.5 * 2 ** -9, 460.0, 1e9, -1e9]))).tolist() == \
+        [16.0, 20.0, 20.0, 2 * 2.0 ** -9, 2 * 2.0 ** -9, 448.0, 448.0, -448.0]
+    q, sc = F.quantize_rows(np.array([[0.5, -2.0, 1.0], [0.0, 0.0, 0.0]], np.float32))
+    assert np.allclose(sc, [2.0 / 448, 1.0]) and np.allclose(q[0], [0.5, -2.0, 1.0]) and not q[1].any()
+
+
+def test_fp8_plan_structure_and_rejections(tmp_path, densenet_repo, monkeypatch):
+    """fp8 precision mode (BASELINE configs[4]): e4m3 tensors between the stem and the global pool, halfs for [N, C] vectors, fp32 graph
+    I/O; graphs the fp8 kernels cannot run are rejected at plan time with a reason (never handed to a kernel that would misread bytes)."""
+    monkeypatch.setenv("IE_PRECISION", "fp8")
+    path = models.write_repo(str(tmp_path), "resnet50", models.resnet50("N"))
+    p = B.DescribeModel(path, 4)["plan"]
+    assert p["precision"] == "fp8"
+    convs = [s for s in p["steps"] if s["kind"] == "conv"]
+    assert convs[0]["algo"] == "stem" and not convs[0]["in"]["f8"] and convs[0]["out"]["f8"]
+    assert all(s["algo"] == "igemm_f8" and s["in"]["f8"] and s["out"]["f8"] for s in convs[1:-1]) and len(convs) == 54
+    assert sum(1 for s in convs if s["residual"]) == 16 and all(s["in2"]["f8"] for s in convs if s["residual"])
+    gap = [s for s in p["steps"] if s["kind"] == "gap"][0]
+    assert gap["in"]["f8"] and gap["out"]["f16"] and convs[-1]["in"]["f16"] and not convs[-1]["out"]["f16"] and not convs[-1]["out"]["f8"]
+    assert all(s["in_src"] >= 0 for s in p["steps"][1:]) and p["steps"][0]["in_src"] == -1
+    # e4m3 storage: a quarter of the fp32 activation bytes
+    monkeypatch.setenv("IE_PRECISION", "fp32")
+    p32 = B.DescribeModel(path, 4)["plan"]
+    assert p["activation_bytes"] < 0.3 * p32["activation_bytes"]
+    monkeypatch.setenv("IE_PRECISION", "fp8")
+    with pytest.raises(RuntimeError, match="fp8 precision: .*prologue"):
+        B.DescribeModel(os.path.join(densenet_repo, "densenet_onnx", "1"), 2)
+    with pytest.raises(RuntimeError, match="fp8 precision"):
+        B.DescribeModel(models.write_repo(str(tmp_path), "blk", models.resnet_block(2)), 2)
