@@ -116,20 +116,170 @@ def cpu_baseline(sample_images: int, model: str = "densenet121", backend: str = 
                       f"stand-in for the absent ONNX Runtime CPU EP"}
 
 
+DTYPES = {"f32": ("fp32", "fp32", PEAK_FP32_MFMA_TFLOPS), "f16": ("fp16", "fp16 (half activations/weights, fp32 accumulate)", PEAK_FP16_MFMA_TFLOPS),
+          "f8": ("fp8", "fp8 (OCP e4m3 activations/weights with calibrated scales, fp32 accumulate)", 5000.0)}   # dense MFMA peak per dtype (no sparsity)
+BASELINE_CONFIG = {("densenet121", "f32"): "BASELINE configs[1]", ("densenet121", "f16"): "BASELINE configs[2]", ("resnet50", "f8"): "BASELINE configs[4]"}
+
+
+def measure(B, models, sharding, *, model_name, dtype, Bsz, steps, warmup, rank, world, local_rank, dist, hostpath, want_detail=True):
+    """Load `model_name` in precision `dtype`, put a synthetic batch into HBM, time K graph replays; returns the JSON-line dict on rank 0."""
+    _, in_name, out_name, arch = MODELS[model_name]
+    if rank == 0:
+        model_dir(model_name)                        # rank 0 writes the synthetic model file once; the others wait for it
+    if dist is not None:
+        dist.barrier()
+    mdir = model_dir(model_name)
+    os.environ["IE_PRECISION"] = DTYPES[dtype][0]
+    model = B.CreateModel(mdir, os.path.basename(os.path.dirname(mdir)), device_id=local_rank)
+    try:
+        din, dout = B.Prepare(model, [[Bsz, 3, 224, 224]], 1)
+        x = models.synthetic_input((Bsz, 3, 224, 224), stream=f"bench/rank{rank}")
+        B.CopyToDevice(model, din[0], x)                 # inputs resident in HBM before any timing
+
+        if dist is not None:                             # load-time weight exchange: one RCCL broadcast over xGMI
+            import torch
+            blob = B.GetWeightBlob(model)
+            sharding.broadcast_weights(dist, blob, src=0)
+            torch.cuda.synchronize()
+            B.WeightsUpdated(model)                      # re-derives the half / fragment-major / e4m3 mirrors from the broadcast blob
+
+        def barrier():
+            B.Synchronize(model)
+            if dist is not None:
+                import torch
+                torch.cuda.synchronize()
+                dist.barrier()
+
+        B.RunPrepared(model, warmup, True)
+        barrier()
+        t0 = time.perf_counter()
+        B.RunPrepared(model, steps, True)           # EXACTLY K steps, back-to-back graph replays, then sync
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            import torch
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+
+        # per-call latency of the device-resident step (sync after every step)
+        lat = []
+        for _ in range(min(steps, 50)):
+            t1 = time.perf_counter()
+            B.RunPrepared(model, 1, True)
+            lat.append((time.perf_counter() - t1) * 1e3)
+        p50 = float(np.percentile(lat, 50))
+
+        y = np.empty((Bsz, 1000), np.float32)
+        B.CopyToHost(model, y, dout[0])
+        assert np.isfinite(y).all()
+        if rank != 0:
+            return None
+        total_images = Bsz * world * steps
+        cfg_name = BASELINE_CONFIG.get((model_name, dtype), "additional configuration")
+        result = {
+            "metric": f"images/sec, {arch} {DTYPES[dtype][0]}, batch {Bsz} per GPU, device-resident inputs (+ p50 step latency)",
+            "value": round(total_images / elapsed, 2), "unit": "images/sec", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": f"{arch} {DTYPES[dtype][1]} batch={Bsz} per GPU, synthetic 3x224x224 inputs ({cfg_name}); "
+                                   "synthetic ONNX graph + seeded random weights (reference model file is not in the mount)",
+                       "global_batch": Bsz * world, "per_gpu_batch": Bsz, "parallelism": f"dp{world} (independent batch shards)"},
+            "p50_ms": round(p50, 4),
+        }
+        # ---- roofline of the dominant kernel family, HIP events on the model's stream --------------------------
+        prof = B.Profile(model, 5)
+        fam = {}
+        for p in prof:
+            k = p["kernel"].split("<")[0]
+            f = fam.setdefault(k, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
+            f["ms"] += p["ms"]; f["flops"] += p["flops"]; f["bytes"] += p["bytes"]; f["launches"] += 1
+        dom = max(fam, key=lambda k: fam[k]["ms"])
+        d = fam[dom]
+        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        traffic, traffic_src = None, None
+        try:      # HBM bytes per launch from the committed PMC pass of the same command (rocprofv3 cannot run inside bench.py)
+            tf = {("densenet121", "f32"): "traffic.json", ("densenet121", "f16"): "traffic_f16_b128.json", ("resnet50", "f8"): "traffic_resnet50_f8_b256.json"}.get((model_name, dtype))
+            rounds = sorted(r_ for r_ in os.listdir(os.path.join(ROOT, "profiles")) if tf and os.path.exists(os.path.join(ROOT, "profiles", r_, tf)))
+            if rounds:
+                traffic_src = os.path.join("profiles", rounds[-1], tf)
+                traffic = json.load(open(os.path.join(ROOT, traffic_src))).get(dom, {}).get("hbm_bytes_per_launch")
+        except Exception:  # noqa: BLE001
+            pass
+        mfma_peak = DTYPES[dtype][2]
+        achieved_gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+        frac_mfma, frac_hbm = achieved / mfma_peak, achieved_gbs / PEAK_HBM_GBS
+        common = {"kernel": dom, "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
+                  "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"], 1), "launches_per_step": d["launches"],
+                  "flops_per_launch": round(d["flops"] / d["launches"], 1), "avg_launch_ms": round(d["ms"] / d["launches"], 6),
+                  "achieved_tflops": round(achieved, 3), "achieved_gbs": round(achieved_gbs, 1),
+                  "frac_of_mfma_peak": round(frac_mfma, 4), "frac_of_hbm_peak": round(frac_hbm, 4)}
+        if frac_mfma >= frac_hbm:      # the ceiling this kernel family is closer to is the one that bounds it
+            result["roofline"] = {"bound": "mfma", "achieved": round(achieved, 3), "peak": mfma_peak, "unit": "TFLOP/s", "frac": round(frac_mfma, 4)}
+        else:
+            result["roofline"] = {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(frac_hbm, 4)}
+        result["roofline"].update(common)
+        if want_detail:
+            result["roofline"]["note"] = (
+                "algorithmic FLOPs (2*M*N*K) and bytes (operands once + result once) summed over the family's launches of one forward / sum "
+                "of their HIP-event durations in an eager instrumented pass on the model's stream; traffic = (2*FETCH_SIZE + WRITE_SIZE) "
+                "from a separate rocprofv3 --pmc pass (gfx950 FETCH_SIZE correction), family average per launch")
+        # SURVEY §8d: the tight per-layer bound  sum_l max(bytes_l / HBM peak, flops_l / MFMA peak of the dtype)
+        tight_ms = sum(max(p["bytes"] / (PEAK_HBM_GBS * 1e9), p["flops"] / (mfma_peak * 1e12)) for p in prof) * 1e3
+        result["roofline_model"] = {"tight_bound_ms_per_step": round(tight_ms, 4), "frac_of_tight_bound": round(tight_ms / (elapsed / steps * 1e3), 4),
+                                    "flops_per_step": sum(p["flops"] for p in prof), "algorithmic_bytes_per_step": sum(p["bytes"] for p in prof)}
+        result["kernel_families_ms"] = {k: round(v["ms"], 4) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
+        result["eager_forward_ms"] = round(sum(p["ms"] for p in prof), 4)
+        # ---- full C-ABI call with host buffers (PCIe-inclusive; reported, never `value`) -----------------------
+        if hostpath:
+            # Two clocks per payload type.  modelinfer_*: time INSIDE the ModelInfer C call with buffers marshalled as the Go binding
+            # has them at the call (fresh C.malloc'ed pageable memory, inference_binding.go:590-651) - what the engine answers for.
+            # binding_*: the whole (*Model).Infer mirror including the binding's own malloc + copy in / copy out, which the build
+            # leaves unchanged (SURVEY a10).
+            outs = [B.OutputConfig(out_name, [Bsz, 1000, 1, 1] if model_name == "densenet121" else [Bsz, 1000])]
+            xb = np.clip(x * 255.0, 0, 255).astype(np.uint8)
+            for tag, ins in (("", [B.TensorData(in_name, B.DataTypeFloat32, B.Shape([Bsz, 3, 224, 224]), x)]),
+                             ("_uint8", [B.TensorData(in_name, B.DataTypeUint8, B.Shape([Bsz, 3, 224, 224]), xb)])):
+                model.InferTimed(ins, outs, 3)
+                before = B.RuntimeInfo(model)
+                tl = model.InferTimed(ins, outs, 15)
+                after = B.RuntimeInfo(model)
+                p50c = float(np.percentile(tl, 50))
+                result[f"modelinfer{tag}_p50_ms"] = round(p50c * 1e3, 3)
+                result[f"modelinfer{tag}_images_per_s"] = round(Bsz / p50c, 1)
+                nfw = max(1, after["forwards"] - before["forwards"])
+                result[f"modelinfer{tag}_device_ms"] = round((after["device_ms_total"] - before["device_ms_total"]) / nfw, 3)
+                if want_detail:
+                    hl = []
+                    for _ in range(8):
+                        t1 = time.perf_counter()
+                        model.Infer(ins, outs)
+                        hl.append(time.perf_counter() - t1)
+                    result[f"binding{tag}_p50_ms"] = round(float(np.percentile(hl, 50)) * 1e3, 3)
+            info = B.RuntimeInfo(model)
+            result["modelinfer_pipeline"] = {"chunks": info["last_chunks"], "head_steps": info["last_head_steps"]}
+        return result
+    finally:
+        model.Destroy()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 32; 128 for f16, 256 for f8)")
     ap.add_argument("--cpu-sample", type=int, default=32, help="images for the CPU baseline (0 = skip)")
     ap.add_argument("--cpu-backend", choices=["auto", "torch", "numpy"], default="auto")
-    ap.add_argument("--dtype", choices=["f32", "f16"], default="f32",
-                    help="f32 = the headline (BASELINE configs[1]); f16 = the fp16 precision mode (configs[2-3], use --batch 128)")
+    ap.add_argument("--dtype", choices=["f32", "f16", "f8"], default="f32",
+                    help="f32 = the headline (BASELINE configs[1]); f16 = the fp16 precision mode (configs[2-3]); f8 = the fp8 mode (configs[4], --model resnet50)")
     ap.add_argument("--model", choices=sorted(MODELS), default="densenet121",
                     help="densenet121 = the headline workload; resnet50 = the second model family (BASELINE configs[4]'s architecture)")
     ap.add_argument("--no-hostpath", action="store_true", help="skip the ModelInfer (PCIe-inclusive) measurement")
+    ap.add_argument("--no-secondary", action="store_true", help="headline only: skip the fp16 B=128 and ResNet-50 fp8 B=256 lines")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = {"f32": 32, "f16": 128, "f8": 256}[args.dtype]
 
     from _pkg import load_package
     load_package()
@@ -153,142 +303,24 @@ def main() -> None:
     if not B.IsCUDAAvailable():
         raise SystemExit("bench.py needs a HIP device (the engine has no CPU fallback)")
 
-    # rank 0 writes the synthetic model file once; the others wait for it
+    common = dict(rank=rank, world=world, local_rank=local_rank, dist=dist)
+    result = measure(B, models, sharding, model_name=args.model, dtype=args.dtype, Bsz=args.batch, steps=args.steps, warmup=args.warmup,
+                     hostpath=not args.no_hostpath, **common)
+    # The other BASELINE configurations that fit one GPU ride on the same line (a few hundred ms each), so they are driver-run
+    # numbers too: DenseNet-121 fp16 B=128 (configs[2]) and ResNet-50 fp8 B=256 (configs[4]).  Only behind the default headline.
+    headline = args.model == "densenet121" and args.dtype == "f32"
+    if headline and not args.no_secondary and world == 1:
+        secondary = []
+        for mname, dt, bsz in (("densenet121", "f16", 128), ("resnet50", "f8", 256)):
+            r = measure(B, models, sharding, model_name=mname, dtype=dt, Bsz=bsz, steps=max(5, args.steps // 2), warmup=max(2, args.warmup // 2),
+                        hostpath=not args.no_hostpath, want_detail=False, **common)
+            if r is not None:
+                secondary.append({k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "p50_ms", "roofline",
+                                                      "roofline_model", "kernel_families_ms") if k in r} |
+                                 {k: v for k, v in r.items() if k.startswith("modelinfer")})
+        if result is not None:
+            result["secondary"] = secondary
     if rank == 0:
-        mdir = model_dir(args.model)
-    if dist is not None:
-        dist.barrier()
-    mdir = model_dir(args.model)
-    _, in_name, out_name, arch = MODELS[args.model]
-
-    os.environ["IE_PRECISION"] = "fp16" if args.dtype == "f16" else "fp32"
-    model = B.CreateModel(mdir, os.path.basename(os.path.dirname(mdir)), device_id=local_rank)
-    Bsz = args.batch
-    din, dout = B.Prepare(model, [[Bsz, 3, 224, 224]], 1)
-    x = models.synthetic_input((Bsz, 3, 224, 224), stream=f"bench/rank{rank}")
-    B.CopyToDevice(model, din[0], x)                 # inputs resident in HBM before any timing
-
-    if dist is not None:                             # load-time weight exchange: one RCCL broadcast over xGMI
-        import torch
-        blob = B.GetWeightBlob(model)
-        sharding.broadcast_weights(dist, blob, src=0)
-        torch.cuda.synchronize()
-        B.WeightsUpdated(model)                      # fp16 mode re-derives its half mirror from the broadcast blob
-
-    def barrier():
-        B.Synchronize(model)
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
-
-    B.RunPrepared(model, args.warmup, True)
-    barrier()
-    t0 = time.perf_counter()
-    B.RunPrepared(model, args.steps, True)           # EXACTLY K steps, back-to-back graph replays, then sync
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # per-call latency of the device-resident step (sync after every step)
-    lat = []
-    for _ in range(min(args.steps, 50)):
-        t1 = time.perf_counter()
-        B.RunPrepared(model, 1, True)
-        lat.append((time.perf_counter() - t1) * 1e3)
-    p50 = float(np.percentile(lat, 50))
-
-    y = np.empty((Bsz, 1000), np.float32)
-    B.CopyToHost(model, y, dout[0])
-    assert np.isfinite(y).all()
-
-    result = None
-    if rank == 0:
-        total_images = Bsz * world * args.steps
-        result = {
-            "metric": f"images/sec, {arch} {'fp32' if args.dtype == 'f32' else 'fp16'}, batch {Bsz} per GPU, device-resident inputs (+ p50 step latency)",
-            "value": round(total_images / elapsed, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{arch} {'fp32' if args.dtype == 'f32' else 'fp16 (half activations/weights, fp32 accumulate)'} batch={Bsz} per GPU, "
-                                   f"synthetic 3x224x224 inputs ({('BASELINE configs[1]' if args.dtype == 'f32' else 'BASELINE configs[2]') if args.model == 'densenet121' else 'second model family'}); "
-                                   "synthetic ONNX graph + seeded random weights (reference model file is not in the mount)",
-                       "global_batch": Bsz * world, "per_gpu_batch": Bsz, "parallelism": f"dp{world} (independent batch shards)"},
-            "p50_ms": round(p50, 4),
-        }
-        # ---- roofline of the dominant kernel family, HIP events on the model's stream --------------------------
-        prof = B.Profile(model, 5)
-        fam = {}
-        for p in prof:
-            k = p["kernel"].split("<")[0]
-            f = fam.setdefault(k, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
-            f["ms"] += p["ms"]; f["flops"] += p["flops"]; f["bytes"] += p["bytes"]; f["launches"] += 1
-        dom = max(fam, key=lambda k: fam[k]["ms"])
-        d = fam[dom]
-        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        traffic, traffic_src = None, None
-        try:      # HBM bytes per launch from the committed PMC pass of the same command (rocprofv3 cannot run inside bench.py)
-            tf = "traffic.json" if args.dtype == "f32" else "traffic_f16_b128.json"
-            rounds = sorted(x for x in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", x, tf)))
-            if rounds:
-                traffic_src = os.path.join("profiles", rounds[-1], tf)
-                traffic = json.load(open(os.path.join(ROOT, traffic_src))).get(dom, {}).get("hbm_bytes_per_launch")
-        except Exception:  # noqa: BLE001
-            pass
-        mfma_peak = PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_FP16_MFMA_TFLOPS
-        achieved_gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
-        frac_mfma, frac_hbm = achieved / mfma_peak, achieved_gbs / PEAK_HBM_GBS
-        common = {"kernel": dom, "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
-                  "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"], 1), "launches_per_step": d["launches"],
-                  "flops_per_launch": round(d["flops"] / d["launches"], 1), "avg_launch_ms": round(d["ms"] / d["launches"], 6),
-                  "achieved_tflops": round(achieved, 3), "achieved_gbs": round(achieved_gbs, 1),
-                  "frac_of_mfma_peak": round(frac_mfma, 4), "frac_of_hbm_peak": round(frac_hbm, 4)}
-        if frac_mfma >= frac_hbm:      # the ceiling this kernel family is closer to is the one that bounds it
-            result["roofline"] = {"bound": "mfma", "achieved": round(achieved, 3), "peak": mfma_peak, "unit": "TFLOP/s", "frac": round(frac_mfma, 4)}
-        else:
-            result["roofline"] = {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(frac_hbm, 4)}
-        result["roofline"].update(common)
-        result["roofline"]["note"] = (
-            "algorithmic FLOPs (2*M*N*K) and bytes (operands once + result once) summed over the family's launches of one forward / sum "
-            "of their HIP-event durations in an eager instrumented pass on the model's stream; traffic = (2*FETCH_SIZE + WRITE_SIZE) "
-            "from a separate rocprofv3 --pmc pass (gfx950 FETCH_SIZE correction), family average per launch")
-        # the tight per-layer bound  sum_l max(bytes_l / HBM peak, flops_l / fp32 MFMA peak)
-        tight_ms = sum(max(p["bytes"] / (PEAK_HBM_GBS * 1e9), p["flops"] / (mfma_peak * 1e12)) for p in prof) * 1e3
-        result["roofline_model"] = {"tight_bound_ms_per_step": round(tight_ms, 4), "frac_of_tight_bound": round(tight_ms / (elapsed / args.steps * 1e3), 4),
-                                    "flops_per_step": sum(p["flops"] for p in prof), "algorithmic_bytes_per_step": sum(p["bytes"] for p in prof)}
-        result["kernel_families_ms"] = {k: round(v["ms"], 4) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
-        result["eager_forward_ms"] = round(sum(p["ms"] for p in prof), 4)
-        # ---- full C-ABI call with host buffers (PCIe-inclusive; reported, never `value`) -----------------------
-        if not args.no_hostpath:
-            # Two clocks per payload type.  modelinfer_*: time INSIDE the ModelInfer C call with buffers marshalled as the Go binding
-            # has them at the call (fresh C.malloc'ed pageable memory, inference_binding.go:590-651) - what the engine answers for.
-            # binding_*: the whole (*Model).Infer mirror including the binding's own malloc + copy in / copy out, which the build
-            # leaves unchanged.
-            outs = [B.OutputConfig(out_name, [Bsz, 1000, 1, 1] if args.model == "densenet121" else [Bsz, 1000])]
-            xb = np.clip(x * 255.0, 0, 255).astype(np.uint8)
-            for tag, ins in (("", [B.TensorData(in_name, B.DataTypeFloat32, B.Shape([Bsz, 3, 224, 224]), x)]),
-                             ("_uint8", [B.TensorData(in_name, B.DataTypeUint8, B.Shape([Bsz, 3, 224, 224]), xb)])):
-                model.InferTimed(ins, outs, 3)
-                before = B.RuntimeInfo(model)
-                tl = model.InferTimed(ins, outs, 15)
-                after = B.RuntimeInfo(model)
-                p50c = float(np.percentile(tl, 50))
-                result[f"modelinfer{tag}_p50_ms"] = round(p50c * 1e3, 3)
-                result[f"modelinfer{tag}_images_per_s"] = round(Bsz / p50c, 1)
-                nfw = max(1, after["forwards"] - before["forwards"])
-                result[f"modelinfer{tag}_device_ms"] = round((after["device_ms_total"] - before["device_ms_total"]) / nfw, 3)
-                hl = []
-                for _ in range(8):
-                    t1 = time.perf_counter()
-                    model.Infer(ins, outs)
-                    hl.append(time.perf_counter() - t1)
-                result[f"binding{tag}_p50_ms"] = round(float(np.percentile(hl, 50)) * 1e3, 3)
-            info = B.RuntimeInfo(model)
-            result["modelinfer_pipeline"] = {"chunks": info["last_chunks"], "head_steps": info["last_head_steps"]}
         if args.cpu_sample > 0 and world == 1:       # reported on rank 0 at N=1 only (the other ranks would idle behind it)
             # the numpy oracle needs ~0.5 s per image: keep its sample small
             nimg = args.cpu_sample if args.cpu_backend != "numpy" else min(args.cpu_sample, 8)
@@ -298,7 +330,6 @@ def main() -> None:
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    model.Destroy()
     if rank == 0:
         print(json.dumps(result))
 
