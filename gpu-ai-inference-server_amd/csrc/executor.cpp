@@ -136,6 +136,7 @@ DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id, 
         if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsStem();
         if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsDirect();
         if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsF8();
+        if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsFused();
     });
     check(g_kernels_err, "InitKernels");
     if (opt.share) {
@@ -519,8 +520,11 @@ void DeviceModel::EnsurePipeline(PlanInstance& pi, bool allow_tune) {
         for (size_t i = 0; i < h; ++i) {
             const Step &a = sub.steps[i], &b = full.steps[i];
             if (a.kind != b.kind || !same_view(a.in, b.in) || !same_view(a.out, b.out) || a.has_in2 != b.has_in2 || (a.has_in2 && !same_view(a.in2, b.in2)) ||
-                a.w_off != b.w_off || a.bias_off != b.bias_off || a.pre_scale_off != b.pre_scale_off || a.pre_shift_off != b.pre_shift_off)
+                a.w_off != b.w_off || a.bias_off != b.bias_off || a.pre_scale_off != b.pre_scale_off || a.pre_shift_off != b.pre_shift_off ||
+                a.parts.size() != b.parts.size())
                 return false;
+            for (size_t q = 0; q < a.parts.size(); ++q)
+                if (!same_view(a.parts[q].in, b.parts[q].in) || !same_view(a.parts[q].out, b.parts[q].out) || a.parts[q].w_off != b.parts[q].w_off) return false;
         }
         // Tensors that cross from the head into the tail: a tail step reads a view that no earlier TAIL step has written.  Range c+1
         // runs its head after range c finished its own, so inside the head a range may overwrite rows of earlier ranges only in
@@ -532,7 +536,11 @@ void DeviceModel::EnsurePipeline(PlanInstance& pi, bool allow_tune) {
             if (f == head_stride.end()) head_stride[v.buf] = image_stride(v);
             else if (f->second != image_stride(v)) f->second = -1;
         };
-        for (size_t i = 0; i < h; ++i) { note(full.steps[i].in); note(full.steps[i].out); if (full.steps[i].has_in2) note(full.steps[i].in2); }
+        for (size_t i = 0; i < h; ++i) {
+            note(full.steps[i].in); note(full.steps[i].out);
+            if (full.steps[i].has_in2) note(full.steps[i].in2);
+            for (const Step& q : full.steps[i].parts) { note(q.in); note(q.out); }
+        }
         std::vector<const View*> tail_written;
         auto covered = [&](const View& v) {      // the union of the tail's earlier writes (concat slices) spans the view's channels
             int64_t pos = v.c_off;
@@ -553,6 +561,13 @@ void DeviceModel::EnsurePipeline(PlanInstance& pi, bool allow_tune) {
                 if (!v || covered(*v)) continue;
                 auto f = head_stride.find(v->buf);
                 if (f != head_stride.end() && (f->second == -1 || f->second != image_stride(*v))) return false;
+            }
+            for (const Step& q : full.steps[i].parts) {      // a fused step also reads its 3x3's input and writes its 3x3's slice
+                if (!covered(q.in)) {
+                    auto f = head_stride.find(q.in.buf);
+                    if (f != head_stride.end() && (f->second == -1 || f->second != image_stride(q.in))) return false;
+                }
+                tail_written.push_back(&q.out);
             }
             tail_written.push_back(&full.steps[i].out);
         }
@@ -611,6 +626,58 @@ void DeviceModel::Autotune(PlanInstance& pi, size_t nsteps, bool allow_search) {
         for (size_t si = 0; si < nsteps && si < pi.plan.steps.size(); ++si) {
             Step& s = pi.plan.steps[si];
             if (s.kind != StepKind::Conv || s.algo == ConvAlgo::Naive || s.algo == ConvAlgo::Stem) continue;
+            if (s.algo == ConvAlgo::DenseFused) {
+                // the parts get their own kernel choices (they are what runs when the fused launcher declines, and the yardstick);
+                // then fused vs split is one more timed choice, cached like the others (tile 1 = fused, 0 = split)
+                PlanInstance tmp;
+                tmp.plan.steps = s.parts;
+                tmp.buffers = pi.buffers;
+                tmp.owned.assign(pi.buffers.size(), 0);
+                tmp.workspace = pi.workspace;
+                tmp.workspace_floats = pi.workspace_floats;
+                tmp.counters = pi.counters;
+                tmp.batch_off = pi.batch_off;
+                for (size_t q = 0; q < tmp.plan.steps.size(); ++q) tmp.plan.steps[q].idx = int(q);
+                Autotune(tmp, tmp.plan.steps.size(), allow_search);
+                for (size_t q = 0; q < s.parts.size(); ++q) { s.parts[q].algo = tmp.plan.steps[q].algo; s.parts[q].tile = tmp.plan.steps[q].tile; s.parts[q].splitk = tmp.plan.steps[q].splitk; }
+                const Step& p3 = s.parts[0];
+                std::vector<int64_t> keyf = {s.out.n * s.out.h * s.out.w, s.out.c, s.in.c, 1, 1, 1, 1, 0, 0, s.in.h, s.in.w, s.in.pitch, s.out.pitch, 0, int64_t(ConvAlgo::DenseFused),
+                                             s.pre_scale_off >= 0, s.bias_off >= 0, p3.in.c, p3.in.pitch, s.tile};
+                int choice = -1;
+                {
+                    std::lock_guard<std::mutex> g(w_->tune_mu);
+                    auto hit = w_->tune_cache.find(keyf);
+                    if (hit != w_->tune_cache.end()) choice = hit->second.first;
+                }
+                if (choice < 0 && allow_search) {
+                    searched = true;
+                    auto time_it = [&](const Step& trial) {
+                        LaunchStep(pi, trial, stream_);
+                        float best_ms = 1e30f;
+                        for (int rep = 0; rep < 3; ++rep) {
+                            if (scrub) check(hipMemsetAsync(scrub, 0, kScrubBytes, stream_), "hipMemsetAsync(scrub)");
+                            check(hipEventRecord(e0, stream_), "hipEventRecord");
+                            LaunchStep(pi, trial, stream_);
+                            check(hipEventRecord(e1, stream_), "hipEventRecord");
+                            check(hipEventSynchronize(e1), "hipEventSynchronize");
+                            float ms = 0;
+                            check(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime");
+                            best_ms = std::min(best_ms, ms);
+                        }
+                        return best_ms;
+                    };
+                    const float t_fused = time_it(s);
+                    Step split = s;
+                    split.tile = 0;
+                    const float t_split = time_it(split);
+                    choice = t_fused <= t_split ? 1 : 0;
+                    std::lock_guard<std::mutex> g(w_->tune_mu);
+                    w_->tune_cache[keyf] = {choice, 1};
+                    w_->tune_dirty = true;
+                }
+                if (choice == 0) s.tile = 0;           // tile 0: ConvDenseFusedEligible declines, the parts run
+                continue;
+            }
             const Step planned = s;                    // the planner's default, kept when nothing better is known
             // the planner's default may already name a specialised kernel: the search starts from the tiled implicit GEMM either way
             if (s.algo == ConvAlgo::Ws1x1 || s.algo == ConvAlgo::Ws3x3 || s.algo == ConvAlgo::Direct || s.algo == ConvAlgo::Raster3x3) {
@@ -902,6 +969,23 @@ void DeviceModel::LaunchStep(const PlanInstance& pi, const Step& s_in, hipStream
     auto wp = [&](int64_t off) -> const float* { return off >= 0 ? wb + off : nullptr; };
     switch (s.kind) {
         case StepKind::Conv: {
+            if (s.algo == ConvAlgo::DenseFused) {
+                // one launch for the 3x3 of dense layer L and the 1x1 of layer L+1; the two plain steps when the fused kernel declines
+                const Step& s3 = s.parts.at(0);
+                ConvArgs a1 = MakeConvArgs(pi, s);
+                FusedArgs f;
+                f.in3 = make_arg(pi, s3.in);
+                f.out3 = make_arg(pi, s3.out);
+                f.wfrag3 = w_->d_weights_frag && s3.w_off >= 0 ? w_->d_weights_frag + s3.w_off : nullptr;
+                f.bias3 = wp(s3.bias_off);
+                f.relu3 = s3.relu;
+                if (ConvDenseFusedEligible(a1, f, s.tile)) check(LaunchConvDenseFused(a1, f, s.tile, stream_), "conv_dense_fused");
+                else {
+                    LaunchStep(pi, s.parts[0], stream_);
+                    LaunchStep(pi, s.parts[1], stream_);
+                }
+                break;
+            }
             ConvArgs a = MakeConvArgs(pi, s);
             // A specialised launcher that declines this operand set (alignment, LDS budget ...) hands the step to the tiled kernel.
             Step fb;
@@ -1008,6 +1092,7 @@ static std::string kernel_label(const Step& s) {
     switch (s.kind) {
         case StepKind::Conv:
             if (s.algo == ConvAlgo::Naive) return "conv_naive_kernel";
+            if (s.algo == ConvAlgo::DenseFused) return "conv_dense_fused_kernel<pb" + std::to_string(s.tile) + ">";
             if (s.algo == ConvAlgo::IgemmF8)
                 return "conv_igemm_f8_kernel<" + std::to_string(kIgemmTiles[s.tile].bm) + "x" + std::to_string(kIgemmTiles[s.tile].bn) + ">";
             if (s.algo == ConvAlgo::Direct) {       // one launcher family, three kernels (kernels_direct.hip): report the one that runs

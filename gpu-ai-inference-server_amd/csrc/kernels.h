@@ -45,6 +45,15 @@ struct ConvArgs {
     int64_t in_bytes = 0;              // filled by LaunchConvIgemm: byte span of the input view (buffer descriptor range)
 };
 
+// The 3x3 half of a fused dense-layer step (kernels_fused.hip): bottleneck tensor in, 32 fresh channels out (the tail of the 1x1's
+// input view), fragment-major 3x3 weights.
+struct FusedArgs {
+    TensorArg in3, out3;
+    const float* wfrag3 = nullptr;
+    const float* bias3 = nullptr;
+    int relu3 = 0;
+};
+
 struct PoolArgs {
     TensorArg in, out;                 // NHWC
     int kh = 1, kw = 1, sh = 1, sw = 1, pt = 0, pl = 0, pb = 0, pr = 0;
@@ -112,6 +121,10 @@ hipError_t InitKernelsDirect();
 bool ConvStemEligible(const ConvArgs& a);
 hipError_t LaunchConvStem(const ConvArgs& a, hipStream_t stream);
 hipError_t InitKernelsStem();
+// Fused dense-layer step (fp32): 3x3 growth conv of layer L + 1x1 bottleneck conv of layer L+1 per 16*pb-pixel tile, one launch.
+bool ConvDenseFusedEligible(const ConvArgs& a, const FusedArgs& f, int pb);
+hipError_t LaunchConvDenseFused(const ConvArgs& a, const FusedArgs& f, int pb, hipStream_t stream);
+hipError_t InitKernelsFused();
 // fp8 precision mode (kernels_f8.hip): implicit GEMM on v_mfma_f32_32x32x16_fp8_fp8 over e4m3 NHWC activations and e4m3 weights,
 // fp32 accumulate, per-channel rescale + bias + e4m3 shortcut + ReLU + re-quantisation in the epilogue.  Tiles 0..6 of kIgemmTiles.
 constexpr int kNumConvF8Tiles = 7;

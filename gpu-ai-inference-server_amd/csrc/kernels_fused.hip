@@ -1,0 +1,335 @@
+// Fused dense-layer step for DenseNet-style blocks on small output grids (fp32): the 3x3 growth conv of layer L and the 1x1
+// bottleneck conv of layer L+1 in ONE launch.
+//
+// Dense blocks 3-4 at batch 32 are a strict chain of 80 latency-bound launches (M = 6272 / 1568 pixels): about a third of the fp32
+// forward is per-launch fixed cost (launch gap, operand preamble, first-load latency, store drain).  The chain cannot be shortened
+// by running layers side by side, but two of its links need no grid-wide dependency: the 1x1 conv of layer L+1 is PER PIXEL, and of
+// its K = C + 32 input channels only the last 32 come from layer L's 3x3 conv -- for the same pixels.  So a workgroup that owns a
+// tile of 16*PB pixels
+//   1. computes the 3x3 conv of layer L for ITS pixels (conv_win_kernel's scheme: the bottleneck window it needs -- one contiguous
+//      run of 16*PB + 2W + 2 NHWC pixel rows written by the PREVIOUS launch -- through LDS, weights from the fragment-major mirror,
+//      K split over the 8 waves, partial tiles summed through LDS in wave order), stores those 32 channels to the block buffer and
+//      keeps them in LDS;
+//   2. runs conv1x1_as_kernel's loop for layer L+1 on its pixel rows: channels [0, C) copied from the block buffer (the loads are
+//      issued BEFORE step 1 and land while it runs), the 32 fresh ones from step 1, BN+ReLU prologue on the way into LDS, weights
+//      streamed through a register ring, each wave 16 of the 128 output channels.
+// No barrier between workgroups, no recomputed halo: launch k reads only what launch k-1 wrote.  The planner emits these steps for a
+// run of dense layers (plan.cpp, "dense fusion"); a block of n layers becomes n+1 launches instead of 2n, and the bottleneck tensor
+// ping-pongs between two buffers (one being read as halo by neighbouring tiles while the other is written).
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace ie {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// PB: 16-pixel blocks per workgroup.  8 waves.  1x1: Cout == 128 (16 per wave).  3x3: stride 1, pad 1, Cout == 32, 9 * Cin3 / 16 <= 72 chunks.
+template <int PB, bool PRE>
+__global__ __launch_bounds__(512) void conv_dense_fused_kernel(const ConvArgs a, const FusedArgs f) {
+    constexpr int WAVES = 8, NT = 64 * WAVES, PX = 16 * PB, D = PB == 1 ? 16 : 8, MAXC3 = 9, TN3 = 2, PP = 32 + 4;
+    constexpr int MAXS = PB == 1 ? 8 : 16;             // staging slots per thread for the old channels: PX * (K - 32) / 4 <= MAXS * NT
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_fused[];
+    const int K = a.in.c, Kold = K - 32, P = K + 4, CH = K >> 4, Cin3 = f.in3.c, P3 = Cin3 + 4;
+    float* const sA = reinterpret_cast<float*>(smem_fused);                        // [PX][P]: the 1x1's activation rows
+    float* const sWin = sA + PX * P;                                               // [npx][P3]: bottleneck window of the 3x3
+    float* const sPart = sWin;                                                     // [WAVES/2][PX][PP] once the window is dead
+
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, gk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = a.in.h, W = a.in.w;
+    const int M = a.in.n * H * W;
+    const int m0 = blockIdx.x * PX;
+    const int ipitch = int(a.in.sw), opitch = int(a.out.sw), bpitch = int(f.in3.sw);
+
+    // ---- (a) bottleneck window loads (issued first: they are waited for first) ----
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(f.in3.p, 0, int((int64_t(M - 1) * bpitch + Cin3) * 4), 0x00020000);
+    const int c4n3 = Cin3 >> 2;
+    const int p_lo = m0 - W - 1;
+    const int npx = PX + 2 * W + 2;
+    const int items3 = npx * c4n3;
+    constexpr int MAXW = 8;                            // window slots per thread: items3 <= MAXW * NT (checked by the launcher)
+    u32x4 wv[MAXW];
+#pragma unroll
+    for (int u = 0; u < MAXW; ++u) {
+        const int idx = tid + u * NT;
+        const int row = idx / c4n3, c4 = idx - row * c4n3;
+        const int p = p_lo + row;
+        wv[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (idx < items3 && p >= 0 && p < M) ? unsigned(p * bpitch + c4 * 4) * 4u : OOB, 0, 0);
+    }
+
+    // ---- (b) the 3x3's weight fragments of this wave's K slice (fragment-major: 1 KiB per load) ----
+    const int cpt3 = Cin3 >> 4, total3 = 9 * cpt3;
+    const int cb = int(int64_t(total3) * wave / WAVES), ce = int(int64_t(total3) * (wave + 1) / WAVES);
+    const __amdgpu_buffer_rsrc_t rs_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(f.wfrag3), 0, 32 * 9 * Cin3 * 4, 0x00020000);
+    u32x4 B3[MAXC3][TN3];
+#pragma unroll
+    for (int i = 0; i < MAXC3; ++i) {
+        const int ch = cb + i;
+#pragma unroll
+        for (int j = 0; j < TN3; ++j)
+            B3[i][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w3, ch < ce ? unsigned((j * total3 + ch) * 64 + lane) * 16u : OOB, 0, 0);
+    }
+
+    // ---- (c) the 1x1's old channels [0, Kold) of this tile's pixel rows: loads only, consumed after the 3x3 ----
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(a.in.p, 0, int((int64_t(M - 1) * ipitch + K) * 4), 0x00020000);
+    const int c4n = Kold >> 2;
+    const int items = PX * c4n;
+    u32x4 xv[MAXS];
+#pragma unroll
+    for (int u = 0; u < MAXS; ++u) {
+        const int idx = tid + u * NT;
+        const int row = idx / c4n, c4 = idx - row * c4n;
+        const int p = m0 + row;
+        xv[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (idx < items && p < M) ? unsigned(p * ipitch + c4 * 4) * 4u : OOB, 0, 0);
+    }
+
+    // ---- (d) window -> LDS ----
+#pragma unroll
+    for (int u = 0; u < MAXW; ++u) {
+        const int idx = tid + u * NT;
+        if (idx < items3) {
+            const int row = idx / c4n3, c4 = idx - row * c4n3;
+            *reinterpret_cast<u32x4*>(sWin + row * P3 + c4 * 4) = wv[u];
+        }
+    }
+    __syncthreads();
+
+    // ---- (e) 3x3 on 16 x 16 x 4 tiles: lane (r, gk) owns pixel r of each pixel block ----
+    f32x4 acc3[PB][TN3];
+    bool mok[PB];
+    int oy[PB], ox[PB];
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+        const int m = m0 + pb * 16 + r;
+        mok[pb] = m < M;
+        const int rem = (mok[pb] ? m : 0) % (H * W);
+        oy[pb] = rem / W;
+        ox[pb] = rem - oy[pb] * W;
+#pragma unroll
+        for (int j = 0; j < TN3; ++j) acc3[pb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < MAXC3; ++i) {
+        if (cb + i < ce) {                             // wave-uniform
+            const int ch = cb + i;
+            const int tap = ch / cpt3, c0 = (ch - tap * cpt3) * 16;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            f32x4 av[PB];
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) {
+                const bool ok = mok[pb] && unsigned(oy[pb] + ky - 1) < unsigned(H) && unsigned(ox[pb] + kx - 1) < unsigned(W);
+                av[pb] = *reinterpret_cast<const f32x4*>(sWin + (pb * 16 + r + ky * W + kx) * P3 + c0 + gk * 4);
+                if (!ok) av[pb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int j = 0; j < TN3; ++j) {
+                const f32x4 bv = __builtin_bit_cast(f32x4, B3[i][j]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int pb = 0; pb < PB; ++pb) acc3[pb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[e], av[pb][e], acc3[pb][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- (f) prime the 1x1's weight ring (its latency hides behind the reduction and the staging below) ----
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wfrag), 0, 128 * K * 4, 0x00020000);
+    u32x4 ring[D];
+    int c_l = 0;
+    auto issue = [&](int slot) {
+        ring[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, c_l < CH ? unsigned((wave * CH + c_l) * 64 + lane) * 16u : OOB, 0, 0);
+        ++c_l;
+    };
+#pragma unroll
+    for (int s = 0; s < D; ++s) issue(s);
+
+    // ---- (g) sum the eight partial 3x3 tiles in wave order: waves 4..7 publish, waves 0..3 add theirs and publish ----
+    __syncthreads();                                   // every wave is done reading the window
+    if (wave >= WAVES / 2) {
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+            for (int j = 0; j < TN3; ++j) *reinterpret_cast<f32x4*>(sPart + ((wave - WAVES / 2) * PX + pb * 16 + r) * PP + j * 16 + 4 * gk) = acc3[pb][j];
+    }
+    __syncthreads();
+    if (wave < WAVES / 2) {
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+            for (int j = 0; j < TN3; ++j) {
+                float* const q = sPart + (wave * PX + pb * 16 + r) * PP + j * 16 + 4 * gk;
+                const f32x4 o = *reinterpret_cast<const f32x4*>(q);
+                *reinterpret_cast<f32x4*>(q) = f32x4{acc3[pb][j][0] + o[0], acc3[pb][j][1] + o[1], acc3[pb][j][2] + o[2], acc3[pb][j][3] + o[3]};
+            }
+    }
+
+    // ---- (h) old channels: prologue, -> sA ----
+#pragma unroll
+    for (int u = 0; u < MAXS; ++u) {
+        const int idx = tid + u * NT;
+        if (idx < items) {
+            const int row = idx / c4n, c4 = idx - row * c4n;
+            f32x4 x = __builtin_bit_cast(f32x4, xv[u]);
+            if constexpr (PRE) {
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(a.pre_scale + c4 * 4);
+                const f32x4 sf = *reinterpret_cast<const f32x4*>(a.pre_shift + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float y = x[e] * sc[e] + sf[e];
+                    x[e] = a.pre_relu ? fmaxf(y, 0.f) : y;
+                }
+            }
+            *reinterpret_cast<f32x4*>(sA + row * P + c4 * 4) = x;
+        }
+    }
+    __syncthreads();
+
+    // ---- (i) fresh channels: final sum, 3x3 epilogue, raw value to the block buffer, prologue'd value to sA ----
+    {
+        const __amdgpu_buffer_rsrc_t rs_o3 = __builtin_amdgcn_make_buffer_rsrc(f.out3.p, 0, int((int64_t(M - 1) * int(f.out3.sw) + 32) * 4), 0x00020000);
+        for (int idx = tid; idx < PX * 16; idx += NT) {
+            const int p = idx >> 4, c2 = (idx & 15) * 2;
+            f32x2 v = {0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < WAVES / 2; ++w) {
+                const f32x2 x = *reinterpret_cast<const f32x2*>(sPart + (w * PX + p) * PP + c2);
+                v[0] += x[0];
+                v[1] += x[1];
+            }
+            if (f.bias3 != nullptr) { v[0] += f.bias3[c2]; v[1] += f.bias3[c2 + 1]; }
+            if (f.relu3) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); }
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs_o3, m0 + p < M ? unsigned((m0 + p) * int(f.out3.sw) + c2) * 4u : OOB, 0, 0);
+            if constexpr (PRE) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float y = v[e] * a.pre_scale[Kold + c2 + e] + a.pre_shift[Kold + c2 + e];
+                    v[e] = a.pre_relu ? fmaxf(y, 0.f) : y;
+                }
+            }
+            *reinterpret_cast<f32x2*>(sA + p * P + Kold + c2) = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- (k) the 1x1: conv1x1_as_kernel's loop, 16 output channels per wave ----
+    f32x4 acc[PB];
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) acc[pb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int c_c = 0;
+    const float* const arow = sA + r * P + gk * 4;
+    f32x4 avn[PB];
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) avn[pb] = *reinterpret_cast<const f32x4*>(arow + pb * 16 * P);
+    auto compute = [&](int slot) {
+        f32x4 av[PB];
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) av[pb] = avn[pb];
+        const float* const nxt = arow + (c_c + 1 < CH ? c_c + 1 : c_c) * 16;
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) avn[pb] = *reinterpret_cast<const f32x4*>(nxt + pb * 16 * P);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb)
+                acc[pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(f32x4, ring[slot])[e], av[pb][e], acc[pb], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, PB, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * PB, 0);
+        ++c_c;
+    };
+    const int full = CH / D, rem = CH - full * D;
+    for (int it = 0; it < full; ++it) {
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+            compute(s);
+            issue(s);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+        if (s < rem) compute(s);
+
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out.p, 0, int((int64_t(M - 1) * opitch + 128) * 4), 0x00020000);
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+        const int m = m0 + pb * 16 + r;
+        const int n = wave * 16 + 4 * gk;
+        f32x4 v = acc[pb];
+        if (a.bias != nullptr) {
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += bq[e];
+        }
+        if (a.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_out, m < M ? unsigned(m * opitch + n) * 4u : OOB, 0, 0);
+    }
+}
+
+static size_t fused_lds_bytes(const ConvArgs& a, const FusedArgs& f, int pb) {
+    const size_t px = size_t(16) * pb;
+    const size_t win = (px + 2 * a.in.w + 2) * (f.in3.c + 4) * 4, part = size_t(4) * px * 36 * 4;
+    return px * (a.in.c + 4) * 4 + (win > part ? win : part);
+}
+
+static bool dense(const TensorArg& t) { return t.sc == 1 && t.sh == t.w * t.sw && t.sn == t.h * t.sh; }
+
+bool ConvDenseFusedEligible(const ConvArgs& a, const FusedArgs& f, int pb) {
+    if (pb != 1 && pb != 2) return false;
+    if (a.in.f16 || a.out.f16 || a.in.f8 || a.out.f8 || f.in3.f16 || f.out3.f16 || f.in3.f8 || f.out3.f8) return false;
+    if (a.wfrag == nullptr || f.wfrag3 == nullptr || a.res.p != nullptr) return false;
+    if (a.kh != 1 || a.kw != 1 || a.sh != 1 || a.sw != 1 || a.pt != 0 || a.pl != 0) return false;
+    if (a.out.c != 128 || f.out3.c != 32 || a.in.c < 48 || (a.in.c % 16) || (f.in3.c % 16)) return false;
+    const int total3 = 9 * (f.in3.c / 16);
+    if (total3 > 72 || total3 < 8) return false;
+    // same pixel grid everywhere
+    for (const TensorArg* t : {&a.out, &f.in3, &f.out3})
+        if (t->n != a.in.n || t->h != a.in.h || t->w != a.in.w) return false;
+    if (!dense(a.in) || !dense(a.out) || !dense(f.in3) || !dense(f.out3)) return false;
+    // the fresh 32 channels are the tail of the 1x1's input view, in the same buffer rows
+    if (f.out3.sw != a.in.sw || f.out3.p != a.in.p + (a.in.c - 32)) return false;
+    if ((a.in.sw % 4) || (a.out.sw % 4) || (f.in3.sw % 4) || (f.out3.sw % 2)) return false;
+    for (const void* p : {static_cast<const void*>(a.in.p), static_cast<const void*>(a.out.p), static_cast<const void*>(f.in3.p), static_cast<const void*>(a.wfrag),
+                          static_cast<const void*>(f.wfrag3)})
+        if (reinterpret_cast<uintptr_t>(p) & 15) return false;
+    if (reinterpret_cast<uintptr_t>(f.out3.p) & 7) return false;
+    if (a.bias && (reinterpret_cast<uintptr_t>(a.bias) & 15)) return false;
+    if (a.pre_scale && ((reinterpret_cast<uintptr_t>(a.pre_scale) & 15) || (reinterpret_cast<uintptr_t>(a.pre_shift) & 15))) return false;
+    const int64_t M = int64_t(a.in.n) * a.in.h * a.in.w;
+    if (M > 65536 || (M + 64) * a.in.sw * 4 >= (int64_t(1) << 31) || M * a.out.sw * 4 >= (int64_t(1) << 31) || (M + 64) * f.in3.sw * 4 >= (int64_t(1) << 31)) return false;
+    const int px = 16 * pb;
+    if (int64_t(px) * ((a.in.c - 32) / 4) > int64_t(pb == 1 ? 8 : 16) * 512) return false;        // staging slots
+    if (int64_t(px + 2 * a.in.w + 2) * (f.in3.c / 4) > int64_t(8) * 512) return false;            // window slots
+    return fused_lds_bytes(a, f, pb) <= size_t(160) * 1024;
+}
+
+hipError_t LaunchConvDenseFused(const ConvArgs& a, const FusedArgs& f, int pb, hipStream_t stream) {
+    if (!ConvDenseFusedEligible(a, f, pb)) return hipErrorInvalidValue;
+    const int64_t M = int64_t(a.in.n) * a.in.h * a.in.w;
+    const dim3 grid(unsigned((M + 16 * pb - 1) / (16 * pb)));
+    const size_t lds = fused_lds_bytes(a, f, pb);
+    if (pb == 1) {
+        if (a.pre_scale) conv_dense_fused_kernel<1, true><<<grid, dim3(512), lds, stream>>>(a, f);
+        else conv_dense_fused_kernel<1, false><<<grid, dim3(512), lds, stream>>>(a, f);
+    } else {
+        if (a.pre_scale) conv_dense_fused_kernel<2, true><<<grid, dim3(512), lds, stream>>>(a, f);
+        else conv_dense_fused_kernel<2, false><<<grid, dim3(512), lds, stream>>>(a, f);
+    }
+    return hipGetLastError();
+}
+
+hipError_t InitKernelsFused() {
+    hipError_t e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dense_fused_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dense_fused_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dense_fused_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dense_fused_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+}  // namespace ie

@@ -750,6 +750,22 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
         last_use[r] = std::max(last_use[r], int(pos));
         for (int x : n.in) { int rx = L.vals[x].root; last_use[rx] = std::max(last_use[rx], int(pos)); used[rx] = 1; }
     }
+    // Dense fusion (see the pass after step emission): when a 3x3 conv and the 1x1 conv behind it will run as ONE launch, the 3x3's
+    // input (the bottleneck tensor, read as halo by neighbouring tiles) must outlive the launch that also writes the next
+    // bottleneck: keep it live one position longer so the two never share a buffer.
+    if (precision == Precision::F32 && !std::getenv("IE_NO_DENSE_FUSE"))
+        for (size_t pos = 0; pos + 1 < order.size(); ++pos) {
+            const LNode& a3 = L.nodes[order[pos]];
+            size_t nxt = pos + 1;                      // Concat / alias nodes emit nothing: the launch behind the 3x3 is the next real node
+            while (nxt < order.size() && (L.nodes[order[nxt]].kind == L_CONCAT || L.nodes[order[nxt]].kind == L_ALIAS)) ++nxt;
+            if (nxt >= order.size()) break;
+            const LNode& b1 = L.nodes[order[nxt]];
+            if (a3.kind != L_CONV || b1.kind != L_CONV || a3.kh != 3 || a3.kw != 3 || b1.kh != 1 || b1.kw != 1 || a3.has_pre) continue;
+            if (L.vals[a3.out].c != 32 || L.vals[b1.out].c != 128 || L.vals[b1.in[0]].root != L.vals[a3.out].root) continue;
+            if (L.vals[a3.out].n * L.vals[a3.out].h * L.vals[a3.out].w > 8192) continue;
+            const int rb = L.vals[a3.in[0]].root;
+            last_use[rb] = std::max(last_use[rb], int(nxt));
+        }
     for (int v : out_vals) last_use[L.vals[v].root] = INF;
     for (size_t v = 0; v < L.vals.size(); ++v) if (L.vals[v].is_input) last_use[L.vals[v].root] = INF;  // staging buffers stay dedicated
 
@@ -1109,6 +1125,65 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
     }
     while (plan.weights.size() % 8) plan.weights.push_back(0.f);
 
+    // ---- dense fusion (fp32, small output grids): 3x3 growth conv of layer L + the 1x1 bottleneck conv of layer L+1 ------------------
+    // Pattern: step i = plain 3x3/s1/p1 conv (no prologue, 32 output channels) writing a channel slice of a concat buffer; step i+1 =
+    // 1x1 conv with 128 output channels whose input view is that buffer's channels [c_off, slice end): its last 32 input channels are
+    // exactly what step i produces, for the same pixels (kernels_fused.hip).  Only where launches are latency-bound (M <= 8192).
+    if (precision == Precision::F32 && !std::getenv("IE_NO_DENSE_FUSE") && !std::getenv("IE_FORCE_ALGO") && !std::getenv("IE_FORCE_TILE")) {
+        std::vector<Step> fusedsteps;
+        for (size_t i = 0; i < plan.steps.size(); ++i) {
+            const Step& s3 = plan.steps[i];
+            bool fuse = false;
+            if (i + 1 < plan.steps.size()) {
+                const Step& s1 = plan.steps[i + 1];
+                const int64_t M = s3.out.n * s3.out.h * s3.out.w;
+                fuse = s3.kind == StepKind::Conv && s1.kind == StepKind::Conv && s3.kh == 3 && s3.kw == 3 && s3.sh == 1 && s3.sw == 1 && s3.pt == 1 && s3.pl == 1 &&
+                       s3.pb == 1 && s3.pr == 1 && s3.pre_scale_off < 0 && !s3.has_in2 && s3.out.c == 32 && s3.in.c % 16 == 0 && 9 * (s3.in.c / 16) <= 72 &&
+                       9 * (s3.in.c / 16) >= 8 && s1.kh == 1 && s1.kw == 1 && s1.sh == 1 && s1.sw == 1 && s1.pt == 0 && s1.pl == 0 && s1.pb == 0 && s1.pr == 0 &&
+                       !s1.has_in2 && s1.out.c == 128 && s1.in.buf == s3.out.buf && s1.in.pitch == s3.out.pitch && !s1.in.nchw && !s3.in.nchw &&
+                       s1.in.c_off + s1.in.c == s3.out.c_off + s3.out.c && s1.in.c >= 48 && s1.in.c % 16 == 0 && s1.in.n == s3.out.n && s1.in.h == s3.out.h &&
+                       s1.in.w == s3.out.w && s1.out.buf != s3.in.buf && M <= 8192 && s3.algo != ConvAlgo::Naive && s1.algo != ConvAlgo::Naive &&
+                       s3.in.pitch % 4 == 0 && s3.in.c_off % 4 == 0 && s1.in.pitch % 4 == 0 && s1.in.c_off % 4 == 0 && s1.out.pitch % 4 == 0 && s1.out.c_off % 4 == 0;
+                if (fuse) {
+                    const int pb = M <= 2048 ? 1 : 2;
+                    const int64_t px = 16 * pb;
+                    const int64_t win = (px + 2 * s3.in.w + 2) * (s3.in.c + 4) * 4, part = 4 * px * 36 * 4;
+                    if (px * (s1.in.c + 4) * 4 + std::max(win, part) > 160 * 1024 || px * ((s1.in.c - 32) / 4) > (pb == 1 ? 8 : 16) * 512 ||
+                        (px + 2 * s3.in.w + 2) * (s3.in.c / 4) > 8 * 512)
+                        fuse = false;
+                    if (fuse) {
+                        Step f = s1;
+                        f.algo = ConvAlgo::DenseFused;
+                        f.tile = pb;
+                        f.splitk = 1;
+                        f.name = s3.name + " | " + s1.name;
+                        f.flops = s3.flops + s1.flops;
+                        f.bytes = s3.bytes + s1.bytes;
+                        f.parts = {s3, s1};
+                        fusedsteps.push_back(std::move(f));
+                        ++i;
+                    }
+                }
+            }
+            if (!fuse) fusedsteps.push_back(s3);
+        }
+        if (fusedsteps.size() != plan.steps.size()) {
+            // renumber: idx, in_src / in2_src follow the new positions (a fused step is the producer of both of its outputs)
+            std::vector<int> remap(plan.steps.size(), -1);
+            for (size_t k = 0; k < fusedsteps.size(); ++k) {
+                if (fusedsteps[k].algo == ConvAlgo::DenseFused) { remap[size_t(fusedsteps[k].parts[0].idx)] = int(k); remap[size_t(fusedsteps[k].parts[1].idx)] = int(k); }
+                else remap[size_t(fusedsteps[k].idx)] = int(k);
+            }
+            for (size_t k = 0; k < fusedsteps.size(); ++k) {
+                Step& st = fusedsteps[k];
+                st.idx = int(k);
+                if (st.in_src >= 0) st.in_src = remap[size_t(st.in_src)];
+                if (st.in2_src >= 0) st.in2_src = remap[size_t(st.in2_src)];
+            }
+            plan.steps = std::move(fusedsteps);
+        }
+    }
+
     // ---- I/O descriptors ---------------------------------------------------------------------------
     for (size_t i = 0; i < m.inputs.size(); ++i) {
         IoDesc d;
@@ -1152,7 +1227,7 @@ static std::string json_escape(const std::string& s) {
 
 std::string PlanToJson(const Plan& p) {
     static const char* kinds[] = {"conv", "pool", "gap", "eltwise", "copy"};
-    static const char* algos[] = {"igemm_vec", "igemm_scalar", "naive", "raster3x3", "ws1x1", "ws3x3", "stem", "direct", "igemm_f8"};
+    static const char* algos[] = {"igemm_vec", "igemm_scalar", "naive", "raster3x3", "ws1x1", "ws3x3", "stem", "direct", "igemm_f8", "dense_fused"};
     std::ostringstream o;
     o.precision(17);
     o << "{\"inputs\":[";
@@ -1185,6 +1260,13 @@ std::string PlanToJson(const Plan& p) {
           << ",\"relu\":" << (s.relu ? "true" : "false") << ",\"bias\":" << (s.bias_off >= 0 ? "true" : "false");
         if (s.kind == StepKind::Conv) o << ",\"algo\":\"" << algos[int(s.algo)] << "\",\"tile\":" << s.tile << ",\"splitk\":" << s.splitk;
         if (s.kind == StepKind::Pool) o << ",\"max\":" << (s.pool_max ? "true" : "false");
+        if (!s.parts.empty()) {
+            Plan sub;
+            sub.steps = s.parts;
+            const std::string js = PlanToJson(sub);
+            const size_t b = js.find("\"steps\":[");
+            o << ",\"parts\":" << js.substr(b + 8, js.size() - (b + 8) - 1);
+        }
         o << ",\"idx\":" << s.idx << ",\"in_src\":" << s.in_src << ",\"in2_src\":" << s.in2_src << ",\"w_off\":" << s.w_off << ",\"bias_off\":" << s.bias_off
           << ",\"pre_scale_off\":" << s.pre_scale_off << ",\"pre_shift_off\":" << s.pre_shift_off << ",\"count_include_pad\":" << (s.count_include_pad ? "true" : "false");
         o << ",\"flops\":" << s.flops << ",\"bytes\":" << s.bytes << "}";

@@ -50,7 +50,8 @@ enum class ConvAlgo : int {
     Ws3x3 = 5,        // fp16 mode: weights-stationary 3x3/s1/p1 conv (Cout <= 32), raster window in LDS
     Stem = 6,         // 7x7/s2/p3 conv over the 3-channel NCHW fp32 graph input: LDS window per output tile, weights resident
     Direct = 7,       // small output grids: K split over the waves of a workgroup, operands loaded straight into MFMA fragments
-    IgemmF8 = 8       // fp8 mode: implicit GEMM over e4m3 activations / weights (v_mfma_f32_32x32x16_fp8_fp8)
+    IgemmF8 = 8,      // fp8 mode: implicit GEMM over e4m3 activations / weights (v_mfma_f32_32x32x16_fp8_fp8)
+    DenseFused = 9    // fp32: 3x3 growth conv of dense layer L + 1x1 bottleneck conv of layer L+1 in one launch (Step::parts holds the two convs)
 };
 
 struct Step {
@@ -74,6 +75,10 @@ struct Step {
     int splitk = 1;            // >1: K-tiles split over this many workgroups per output tile (+ reduce kernel)
     int idx = -1;              // position in Plan::steps
     int in_src = -1, in2_src = -1;   // index of the step that produced `in` / `in2` (-1: a graph input); fp8 mode looks the tensors' scales up by it
+    // DenseFused: parts = {the 3x3 conv step, the 1x1 conv step} exactly as the planner emitted them; this step's own fields repeat
+    // the 1x1's (in, out, weights, prologue, epilogue); tile = 16-pixel blocks per workgroup (1 or 2).  The executor launches the
+    // parts one after the other when the fused launcher declines.
+    std::vector<Step> parts;
     double flops = 0;          // algorithmic FLOPs (2*MACs) of this step for the planned shape
     double bytes = 0;          // algorithmic bytes: operands read once + result written once
 };

@@ -88,7 +88,10 @@ def run_plan(plan: dict, blob: np.ndarray, feeds: dict, act_scales=None, fp8: bo
             _view(bufs, v, n)[...] = x.reshape(n, v["c"], v["h"], v["w"])
         else:
             _view(bufs, v, n)[...] = x.reshape(n, v["c"], v["h"] * v["w"])[:, None, :, :].transpose(0, 1, 3, 2).reshape(n, v["h"], v["w"], v["c"])
-    for s in plan["steps"]:
+    steps = []
+    for s in plan["steps"]:          # a fused dense-layer step carries the two convs it replaces: execute those
+        steps.extend(s["parts"] if s.get("parts") else [s])
+    for s in steps:
         vin, vout = s["in"], s["out"]
         xin = _view(bufs, vin, n)
         if vin["nchw"]:

@@ -18,7 +18,7 @@ HDR = os.path.join(ROOT, "include")
 def _declared(header):
     txt = open(os.path.join(HDR, header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return re.findall(r"^\s*(?:const\s+)?[A-Za-z_][\w\s\*]*?\b([A-Z][A-Za-z]+)\s*\([^;{]*\)\s*;", txt, flags=re.M)
+    return re.findall(r"^\s*(?:const\s+)?[A-Za-z_][\w\s\*]*?\b([A-Z][A-Za-z0-9]+)\s*\([^;{]*\)\s*;", txt, flags=re.M)
 
 
 def test_exports_every_declared_symbol(engine_lib):
