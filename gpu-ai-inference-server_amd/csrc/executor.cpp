@@ -241,9 +241,14 @@ void DeviceModel::BuildInstance(PlanInstance& pi, const std::vector<std::vector<
                     w_->act_scale.assign(pi.plan.steps.size(), 0.f);
                 }
             } else if (const char* nf = std::getenv("IE_NO_FRAG_WEIGHTS"); !(nf && std::atoi(nf) != 0)) {
-                for (const Step& st : pi.plan.steps)
+                auto add_region = [&](const Step& st) {
                     if (st.kind == StepKind::Conv && st.w_off >= 0 && st.out.c % 16 == 0 && st.in.c % 16 == 0 && st.kh * st.kw <= 49)
                         w_->frag_regions.push_back({st.w_off, int(st.out.c), st.kh * st.kw, int(st.in.c)});
+                };
+                for (const Step& st : pi.plan.steps) {
+                    if (st.parts.empty()) add_region(st);
+                    else for (const Step& q : st.parts) add_region(q);       // a fused dense-layer step: both of its convs
+                }
                 if (!w_->frag_regions.empty()) {
                     check(hipMalloc(reinterpret_cast<void**>(&w_->d_weights_frag), w_->weight_floats * sizeof(float)), "hipMalloc(weights_frag)");
                     w_->device_bytes += w_->weight_floats * sizeof(float);

@@ -1507,3 +1507,34 @@ def test_fp8_rejects_graphs_it_cannot_run(densenet_repo):
         with pytest.raises(RuntimeError, match="fp8 precision"):
             B.CreateModel(os.path.join(densenet_repo, "densenet_onnx", "1"), "densenet_onnx")
     _run_with_env(dict(IE_PRECISION="fp8"), go)
+
+
+@pytest.mark.parametrize("batch,image,blocks", [(2, 64, (3, 4)), (5, 56, (2, 3, 2)), (32, 28, (4,))])
+def test_fused_dense_layer_kernel(tmp_path, batch, image, blocks):
+    """conv_dense_fused_kernel (3x3 growth conv of layer L + 1x1 bottleneck conv of layer L+1 in one launch) on DenseNet-shaped
+    graphs with growth 32 / bottleneck 128: both pixel-tile sizes, image widths 16 / 14 / 8 / 7 / 4, ragged last tiles, against the
+    float64 oracle; and bit-for-bit determinism plus agreement with the unfused plan (IE_NO_DENSE_FUSE=1)."""
+    mb = models.densenet(batch, growth=32, blocks=blocks, stem=64, image=image, classes=12, seed=31)
+    path = models.write_repo(str(tmp_path), "fused", mb)
+    x = models.synthetic_input((batch, 3, image, image), stream="fused")
+    ref = O.run(O.load_model(mb), {"data_0": x}, dtype=np.float64)["fc6_1"]
+
+    def go():
+        plan = B.DescribeModel(path, batch)["plan"]
+        m = B.CreateModel(path, "fused")
+        try:
+            y = infer(m, "", "data_0", x, "fc6_1", [batch, 12, 1, 1])[0].copy()
+            y2 = infer(m, "", "data_0", x, "fc6_1", [batch, 12, 1, 1])[0]
+            prof = B.Profile(m, 1) if False else None
+        finally:
+            m.Destroy()
+        np.testing.assert_array_equal(y, y2)
+        return plan, y
+    plan, y = _run_with_env(dict(IE_AUTOTUNE="0"), go)
+    nf = [s for s in plan["steps"] if s.get("algo") == "dense_fused"]
+    assert len(nf) >= sum(b - 1 for b in blocks) - 2, (len(nf), blocks)
+    plan0, y0 = _run_with_env(dict(IE_AUTOTUNE="0", IE_NO_DENSE_FUSE="1"), go)
+    assert not [s for s in plan0["steps"] if s.get("algo") == "dense_fused"]
+    e, e0 = rel_err(y, ref), rel_err(y0, ref)
+    print(f"fused dense layers B={batch} image={image}: {len(nf)} fused steps (tiles {sorted({s['tile'] for s in nf})}), rel err {e:.2e} (unfused {e0:.2e})")
+    assert e < RTOL and e0 < RTOL and rel_err(y, y0) < 2e-5
