@@ -1509,7 +1509,7 @@ def test_fp8_rejects_graphs_it_cannot_run(densenet_repo):
     _run_with_env(dict(IE_PRECISION="fp8"), go)
 
 
-@pytest.mark.parametrize("batch,image,blocks", [(2, 64, (3, 4)), (5, 56, (2, 3, 2)), (32, 28, (4,))])
+@pytest.mark.parametrize("batch,image,blocks", [(2, 64, (3, 4)), (5, 56, (2, 3, 2)), (32, 28, (4,)), (8, 112, (3, 2)), (3, 104, (2, 2))])
 def test_fused_dense_layer_kernel(tmp_path, batch, image, blocks):
     """conv_dense_fused_kernel (3x3 growth conv of layer L + 1x1 bottleneck conv of layer L+1 in one launch) on DenseNet-shaped
     graphs with growth 32 / bottleneck 128: both pixel-tile sizes, image widths 16 / 14 / 8 / 7 / 4, ragged last tiles, against the
