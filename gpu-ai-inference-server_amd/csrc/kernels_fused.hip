@@ -18,6 +18,8 @@
 // ping-pongs between two buffers (one being read as halo by neighbouring tiles while the other is written).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace ie {
@@ -72,21 +74,38 @@ __global__ __launch_bounds__(512) void conv_dense_fused_kernel(const ConvArgs a,
         const int ch = cb + i;
 #pragma unroll
         for (int j = 0; j < TN3; ++j)
-            B3[i][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w3, ch < ce ? unsigned((j * total3 + ch) * 64 + lane) * 16u : OOB, 0, 0);
+            B3[i][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w3, (ch < ce && !(a.debug & 4)) ? unsigned((j * total3 + ch) * 64 + lane) * 16u : OOB, 0, 0);
     }
 
-    // ---- (c) the 1x1's old channels [0, Kold) of this tile's pixel rows: loads only, consumed after the 3x3 ----
+    // ---- (c) the 1x1's old channels [0, Kold) of this tile's pixel rows: loads only, consumed after the 3x3.  A thread keeps ONE
+    //      4-channel column for all its rows (rows advance by rpp per slot), so the prologue's scale/shift for that column is one pair
+    //      of 16-byte loads issued here, not a dependent global round trip per slot later ----
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(a.in.p, 0, int((int64_t(M - 1) * ipitch + K) * 4), 0x00020000);
     const int c4n = Kold >> 2;
-    const int items = PX * c4n;
+    const int rpp = NT / c4n;                          // rows per pass (>= 1: Kold / 4 <= 512, checked by the launcher)
+    const int xrow0 = tid / c4n, xc4 = tid - xrow0 * c4n;
+    const bool xact = xrow0 < rpp;                     // NT - rpp * c4n threads sit this phase out
     u32x4 xv[MAXS];
 #pragma unroll
     for (int u = 0; u < MAXS; ++u) {
-        const int idx = tid + u * NT;
-        const int row = idx / c4n, c4 = idx - row * c4n;
+        const int row = xrow0 + u * rpp;
         const int p = m0 + row;
-        xv[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (idx < items && p < M) ? unsigned(p * ipitch + c4 * 4) * 4u : OOB, 0, 0);
+        xv[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (xact && row < PX && p < M && !(a.debug & 8)) ? unsigned(p * ipitch + xc4 * 4) * 4u : OOB, 0, 0);
     }
+    f32x4 xsc = {1.f, 1.f, 1.f, 1.f}, xsf = {0.f, 0.f, 0.f, 0.f};
+    f32x2 fsc = {1.f, 1.f}, fsf = {0.f, 0.f}, fb3 = {0.f, 0.f};
+    const int fc2 = (tid & 15) * 2;                    // this thread's channel pair of the fresh 32 (phase i)
+    if constexpr (PRE) {
+        if (xact) {
+            xsc = *reinterpret_cast<const f32x4*>(a.pre_scale + xc4 * 4);
+            xsf = *reinterpret_cast<const f32x4*>(a.pre_shift + xc4 * 4);
+        }
+        fsc = *reinterpret_cast<const f32x2*>(a.pre_scale + Kold + fc2);
+        fsf = *reinterpret_cast<const f32x2*>(a.pre_shift + Kold + fc2);
+    }
+    if (f.bias3 != nullptr) fb3 = *reinterpret_cast<const f32x2*>(f.bias3 + fc2);
+    f32x4 ebias = {0.f, 0.f, 0.f, 0.f};                // the 1x1's epilogue bias for this lane's 4 output channels
+    if (a.bias != nullptr) ebias = *reinterpret_cast<const f32x4*>(a.bias + wave * 16 + 4 * gk);
 
     // ---- (d) window -> LDS ----
 #pragma unroll
@@ -115,7 +134,7 @@ __global__ __launch_bounds__(512) void conv_dense_fused_kernel(const ConvArgs a,
     }
 #pragma unroll
     for (int i = 0; i < MAXC3; ++i) {
-        if (cb + i < ce) {                             // wave-uniform
+        if (cb + i < ce && !(a.debug & 1)) {           // wave-uniform (debug bits: timing-only ablations, wrong results)
             const int ch = cb + i;
             const int tap = ch / cpt3, c0 = (ch - tap * cpt3) * 16;
             const int ky = tap / 3, kx = tap - ky * 3;
@@ -142,7 +161,7 @@ __global__ __launch_bounds__(512) void conv_dense_fused_kernel(const ConvArgs a,
     u32x4 ring[D];
     int c_l = 0;
     auto issue = [&](int slot) {
-        ring[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, c_l < CH ? unsigned((wave * CH + c_l) * 64 + lane) * 16u : OOB, 0, 0);
+        ring[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (c_l < CH && !(a.debug & 16)) ? unsigned((wave * CH + c_l) * 64 + lane) * 16u : OOB, 0, 0);
         ++c_l;
     };
 #pragma unroll
@@ -169,22 +188,21 @@ __global__ __launch_bounds__(512) void conv_dense_fused_kernel(const ConvArgs a,
     }
 
     // ---- (h) old channels: prologue, -> sA ----
+    if (xact) {
 #pragma unroll
-    for (int u = 0; u < MAXS; ++u) {
-        const int idx = tid + u * NT;
-        if (idx < items) {
-            const int row = idx / c4n, c4 = idx - row * c4n;
-            f32x4 x = __builtin_bit_cast(f32x4, xv[u]);
-            if constexpr (PRE) {
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(a.pre_scale + c4 * 4);
-                const f32x4 sf = *reinterpret_cast<const f32x4*>(a.pre_shift + c4 * 4);
+        for (int u = 0; u < MAXS; ++u) {
+            const int row = xrow0 + u * rpp;
+            if (row < PX) {
+                f32x4 x = __builtin_bit_cast(f32x4, xv[u]);
+                if constexpr (PRE) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float y = x[e] * sc[e] + sf[e];
-                    x[e] = a.pre_relu ? fmaxf(y, 0.f) : y;
+                    for (int e = 0; e < 4; ++e) {
+                        const float y = x[e] * xsc[e] + xsf[e];
+                        x[e] = a.pre_relu ? fmaxf(y, 0.f) : y;
+                    }
                 }
+                *reinterpret_cast<f32x4*>(sA + row * P + xc4 * 4) = x;
             }
-            *reinterpret_cast<f32x4*>(sA + row * P + c4 * 4) = x;
         }
     }
     __syncthreads();
@@ -201,13 +219,14 @@ __global__ __launch_bounds__(512) void conv_dense_fused_kernel(const ConvArgs a,
                 v[0] += x[0];
                 v[1] += x[1];
             }
-            if (f.bias3 != nullptr) { v[0] += f.bias3[c2]; v[1] += f.bias3[c2 + 1]; }
+            v[0] += fb3[0];
+            v[1] += fb3[1];
             if (f.relu3) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); }
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs_o3, m0 + p < M ? unsigned((m0 + p) * int(f.out3.sw) + c2) * 4u : OOB, 0, 0);
             if constexpr (PRE) {
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    const float y = v[e] * a.pre_scale[Kold + c2 + e] + a.pre_shift[Kold + c2 + e];
+                    const float y = v[e] * fsc[e] + fsf[e];
                     v[e] = a.pre_relu ? fmaxf(y, 0.f) : y;
                 }
             }
@@ -241,7 +260,7 @@ __global__ __launch_bounds__(512) void conv_dense_fused_kernel(const ConvArgs a,
         __builtin_amdgcn_sched_group_barrier(0x008, 4 * PB, 0);
         ++c_c;
     };
-    const int full = CH / D, rem = CH - full * D;
+    const int full = (a.debug & 2) ? 0 : CH / D, rem = (a.debug & 2) ? 0 : CH - (CH / D) * D;
     for (int it = 0; it < full; ++it) {
 #pragma unroll
         for (int s = 0; s < D; ++s) {
@@ -259,11 +278,8 @@ __global__ __launch_bounds__(512) void conv_dense_fused_kernel(const ConvArgs a,
         const int m = m0 + pb * 16 + r;
         const int n = wave * 16 + 4 * gk;
         f32x4 v = acc[pb];
-        if (a.bias != nullptr) {
-            const f32x4 bq = *reinterpret_cast<const f32x4*>(a.bias + n);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += bq[e];
-        }
+        for (int e = 0; e < 4; ++e) v[e] += ebias[e];
         if (a.relu) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -304,13 +320,20 @@ bool ConvDenseFusedEligible(const ConvArgs& a, const FusedArgs& f, int pb) {
     const int64_t M = int64_t(a.in.n) * a.in.h * a.in.w;
     if (M > 65536 || (M + 64) * a.in.sw * 4 >= (int64_t(1) << 31) || M * a.out.sw * 4 >= (int64_t(1) << 31) || (M + 64) * f.in3.sw * 4 >= (int64_t(1) << 31)) return false;
     const int px = 16 * pb;
-    if (int64_t(px) * ((a.in.c - 32) / 4) > int64_t(pb == 1 ? 8 : 16) * 512) return false;        // staging slots
+    {   // staging slots: a thread keeps one 4-channel column, rows advance by rpp = 512 / columns per slot
+        const int c4n = (a.in.c - 32) / 4;
+        if (c4n > 512 || (px + 512 / c4n - 1) / (512 / c4n) > (pb == 1 ? 8 : 16)) return false;
+    }
+    if ((a.in.c - 32) % 4 || (reinterpret_cast<uintptr_t>(a.pre_scale) & 15) || (f.bias3 && (reinterpret_cast<uintptr_t>(f.bias3) & 7))) return false;
     if (int64_t(px + 2 * a.in.w + 2) * (f.in3.c / 4) > int64_t(8) * 512) return false;            // window slots
     return fused_lds_bytes(a, f, pb) <= size_t(160) * 1024;
 }
 
-hipError_t LaunchConvDenseFused(const ConvArgs& a, const FusedArgs& f, int pb, hipStream_t stream) {
-    if (!ConvDenseFusedEligible(a, f, pb)) return hipErrorInvalidValue;
+hipError_t LaunchConvDenseFused(const ConvArgs& a_in, const FusedArgs& f, int pb, hipStream_t stream) {
+    if (!ConvDenseFusedEligible(a_in, f, pb)) return hipErrorInvalidValue;
+    ConvArgs a = a_in;
+    static const int dbg = [] { const char* e = std::getenv("IE_DEBUG_ABLATE"); return e ? std::atoi(e) : 0; }();
+    a.debug = dbg;      // timing-only ablations (wrong results): 1 no 3x3 MFMAs, 2 no 1x1 loop, 4 no 3x3 weight loads, 8 no old-channel loads, 16 no 1x1 weight loads
     const int64_t M = int64_t(a.in.n) * a.in.h * a.in.w;
     const dim3 grid(unsigned((M + 16 * pb - 1) / (16 * pb)));
     const size_t lds = fused_lds_bytes(a, f, pb);

@@ -1148,7 +1148,8 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                     const int pb = M <= 2048 ? 1 : 2;
                     const int64_t px = 16 * pb;
                     const int64_t win = (px + 2 * s3.in.w + 2) * (s3.in.c + 4) * 4, part = 4 * px * 36 * 4;
-                    if (px * (s1.in.c + 4) * 4 + std::max(win, part) > 160 * 1024 || px * ((s1.in.c - 32) / 4) > (pb == 1 ? 8 : 16) * 512 ||
+                    const int64_t c4n = (s1.in.c - 32) / 4, rpp = c4n > 0 && c4n <= 512 ? 512 / c4n : 0;
+                    if (px * (s1.in.c + 4) * 4 + std::max(win, part) > 160 * 1024 || rpp == 0 || (px + rpp - 1) / rpp > (pb == 1 ? 8 : 16) ||
                         (px + 2 * s3.in.w + 2) * (s3.in.c / 4) > 8 * 512)
                         fuse = false;
                     if (fuse) {
