@@ -31,15 +31,16 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // PB: 16-pixel blocks per workgroup.  8 waves.  1x1: Cout == 128 (16 per wave).  3x3: stride 1, pad 1, Cout == 32, 9 * Cin3 / 16 <= 72 chunks.
 template <int PB, bool PRE>
-__global__ __launch_bounds__(512) void conv_dense_fused_kernel(const ConvArgs a, const FusedArgs f) {
-    constexpr int WAVES = 8, NT = 64 * WAVES, PX = 16 * PB, D = PB == 1 ? 16 : 8, MAXC3 = 9, TN3 = 2, PP = 32 + 4;
+__global__ __launch_bounds__(512) void conv_dense_fused_kernel(const ConvArgs a, const FusedArgs f, const int part_off) {
+    constexpr int WAVES = 8, NT = 64 * WAVES, PX = 16 * PB, D = 8, MAXC3 = 9, TN3 = 2, PP = 32 + 4;
     constexpr int MAXS = PB == 1 ? 8 : 16;             // staging slots per thread for the old channels: PX * (K - 32) / 4 <= MAXS * NT
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_fused[];
     const int K = a.in.c, Kold = K - 32, P = K + 4, CH = K >> 4, Cin3 = f.in3.c, P3 = Cin3 + 4;
     float* const sA = reinterpret_cast<float*>(smem_fused);                        // [PX][P]: the 1x1's activation rows
-    float* const sWin = sA + PX * P;                                               // [npx][P3]: bottleneck window of the 3x3
-    float* const sPart = sWin;                                                     // [WAVES/2][PX][PP] once the window is dead
+    float* const sWin = sA;                                                        // [npx][P3]: bottleneck window of the 3x3; sA's rows are only
+                                                                                   // written once every wave is done with the window
+    float* const sPart = sA + part_off;                                            // [WAVES/2][PX][PP], behind max(sA, sWin)
 
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, gk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -168,8 +169,7 @@ __global__ __launch_bounds__(512) void conv_dense_fused_kernel(const ConvArgs a,
     for (int s = 0; s < D; ++s) issue(s);
 
     // ---- (g) sum the eight partial 3x3 tiles in wave order: waves 4..7 publish, waves 0..3 add theirs and publish ----
-    __syncthreads();                                   // every wave is done reading the window
-    if (wave >= WAVES / 2) {
+    if (wave >= WAVES / 2) {                           // (the partial tiles have their own storage: no need to wait for the window's readers)
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
@@ -288,10 +288,14 @@ __global__ __launch_bounds__(512) void conv_dense_fused_kernel(const ConvArgs a,
     }
 }
 
-static size_t fused_lds_bytes(const ConvArgs& a, const FusedArgs& f, int pb) {
+// LDS: the 1x1's rows and the 3x3's window share storage (the rows are staged in registers until the window is dead), the partial
+// tiles of the 3x3 sit behind them.  Returns the partial tiles' offset in floats through part_off.
+static size_t fused_lds_bytes(const ConvArgs& a, const FusedArgs& f, int pb, int* part_off = nullptr) {
     const size_t px = size_t(16) * pb;
-    const size_t win = (px + 2 * a.in.w + 2) * (f.in3.c + 4) * 4, part = size_t(4) * px * 36 * 4;
-    return px * (a.in.c + 4) * 4 + (win > part ? win : part);
+    const size_t rows = px * (a.in.c + 4) * 4, win = (px + 2 * a.in.w + 2) * (f.in3.c + 4) * 4, part = size_t(4) * px * 36 * 4;
+    const size_t first = (rows > win ? rows : win);
+    if (part_off) *part_off = int(first / 4);
+    return first + part;
 }
 
 static bool dense(const TensorArg& t) { return t.sc == 1 && t.sh == t.w * t.sw && t.sn == t.h * t.sh; }
@@ -336,13 +340,14 @@ hipError_t LaunchConvDenseFused(const ConvArgs& a_in, const FusedArgs& f, int pb
     a.debug = dbg;      // timing-only ablations (wrong results): 1 no 3x3 MFMAs, 2 no 1x1 loop, 4 no 3x3 weight loads, 8 no old-channel loads, 16 no 1x1 weight loads
     const int64_t M = int64_t(a.in.n) * a.in.h * a.in.w;
     const dim3 grid(unsigned((M + 16 * pb - 1) / (16 * pb)));
-    const size_t lds = fused_lds_bytes(a, f, pb);
+    int part_off = 0;
+    const size_t lds = fused_lds_bytes(a, f, pb, &part_off);
     if (pb == 1) {
-        if (a.pre_scale) conv_dense_fused_kernel<1, true><<<grid, dim3(512), lds, stream>>>(a, f);
-        else conv_dense_fused_kernel<1, false><<<grid, dim3(512), lds, stream>>>(a, f);
+        if (a.pre_scale) conv_dense_fused_kernel<1, true><<<grid, dim3(512), lds, stream>>>(a, f, part_off);
+        else conv_dense_fused_kernel<1, false><<<grid, dim3(512), lds, stream>>>(a, f, part_off);
     } else {
-        if (a.pre_scale) conv_dense_fused_kernel<2, true><<<grid, dim3(512), lds, stream>>>(a, f);
-        else conv_dense_fused_kernel<2, false><<<grid, dim3(512), lds, stream>>>(a, f);
+        if (a.pre_scale) conv_dense_fused_kernel<2, true><<<grid, dim3(512), lds, stream>>>(a, f, part_off);
+        else conv_dense_fused_kernel<2, false><<<grid, dim3(512), lds, stream>>>(a, f, part_off);
     }
     return hipGetLastError();
 }

@@ -1145,11 +1145,12 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                        s1.in.w == s3.out.w && s1.out.buf != s3.in.buf && M <= 8192 && s3.algo != ConvAlgo::Naive && s1.algo != ConvAlgo::Naive &&
                        s3.in.pitch % 4 == 0 && s3.in.c_off % 4 == 0 && s1.in.pitch % 4 == 0 && s1.in.c_off % 4 == 0 && s1.out.pitch % 4 == 0 && s1.out.c_off % 4 == 0;
                 if (fuse) {
-                    const int pb = M <= 2048 ? 1 : 2;
+                    int pb = M <= 2048 ? 1 : 2;
+                    if (const char* e = std::getenv("IE_FUSE_PB")) { const int v = std::atoi(e); if (v == 1 || v == 2) pb = v; }
                     const int64_t px = 16 * pb;
                     const int64_t win = (px + 2 * s3.in.w + 2) * (s3.in.c + 4) * 4, part = 4 * px * 36 * 4;
                     const int64_t c4n = (s1.in.c - 32) / 4, rpp = c4n > 0 && c4n <= 512 ? 512 / c4n : 0;
-                    if (px * (s1.in.c + 4) * 4 + std::max(win, part) > 160 * 1024 || rpp == 0 || (px + rpp - 1) / rpp > (pb == 1 ? 8 : 16) ||
+                    if (std::max(px * (s1.in.c + 4) * 4, win) + part > 160 * 1024 || rpp == 0 || (px + rpp - 1) / rpp > (pb == 1 ? 8 : 16) ||
                         (px + 2 * s3.in.w + 2) * (s3.in.c / 4) > 8 * 512)
                         fuse = false;
                     if (fuse) {
