@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "kernels.h"
 
@@ -421,7 +422,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_as_kernel(const ConvArgs a
 
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, gk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int K = a.in.c, P = K + 4, CH = K >> 4, Cout = a.out.c;
+    const int K = a.in.c, P = K + (a.debug >> 8), CH = K >> 4, Cout = a.out.c;      // row pad (floats) comes from the launcher
     const int M = a.out.n * a.out.h * a.out.w;
     const int m0 = blockIdx.x * (16 * PB), n0 = blockIdx.y * BN + wave * BNW;
     const int ipitch = int(a.in.sw), opitch = int(a.out.sw);
@@ -563,11 +564,15 @@ static bool as_eligible(const ConvArgs& a, int at) {
 }
 
 template <int AT>
-static hipError_t launch_as_t(const ConvArgs& a, hipStream_t stream) {
+static hipError_t launch_as_t(const ConvArgs& a_in, hipStream_t stream) {
     constexpr AsTile t = kAsTiles[AT];
+    ConvArgs a = a_in;
+    static const int pad = [] { const char* e = std::getenv("IE_AS_PAD"); const int v = e ? std::atoi(e) : 4; return (v >= 4 && v <= 68 && v % 4 == 0) ? v : 4; }();
+    a.debug = pad << 8;
     const int64_t M = int64_t(a.out.n) * a.out.h * a.out.w;
     const dim3 grid(unsigned((M + 16 * t.pb - 1) / (16 * t.pb)), unsigned(a.out.c / (16 * t.tnw * t.waves)));
-    const size_t lds = size_t(16 * t.pb) * (a.in.c + 4) * 4;
+    const size_t lds = size_t(16 * t.pb) * (a.in.c + pad) * 4;
+    if (lds > size_t(160) * 1024) return hipErrorInvalidValue;
     if (a.pre_scale) conv1x1_as_kernel<t.waves, t.tnw, t.pb, true><<<grid, dim3(64 * t.waves), lds, stream>>>(a);
     else conv1x1_as_kernel<t.waves, t.tnw, t.pb, false><<<grid, dim3(64 * t.waves), lds, stream>>>(a);
     return hipGetLastError();

@@ -212,6 +212,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f8_kernel(const ConvA
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int nb = n0 + (wn_i * TN + j) * 32;
+            // shortcut: ONE 16-byte load per lane (the 16 consecutive channels 16*hh .. +15 of its pixel, the layout it will store),
+            // then the inverse of the store exchange hands every lane the four quads it accumulates (channels 8g + 4hh .. +3)
+            unsigned rq[4] = {0u, 0u, 0u, 0u};
+            if (has_res) {                                     // wave-uniform
+                const int n16r = nb + 16 * hh;
+                u32x4 rr = {0u, 0u, 0u, 0u};
+                if (mok && n16r + 15 < Cout) rr = *reinterpret_cast<const u32x4*>(resb + rrow + n16r);
+                const auto t0 = __builtin_amdgcn_permlane32_swap(rr[0], rr[1], false, false);     // lower: {own d0, upper's d0}; upper: {lower's d1, own d1}
+                const auto t1 = __builtin_amdgcn_permlane32_swap(rr[2], rr[3], false, false);
+                rq[0] = t0[0]; rq[2] = t0[1]; rq[1] = t1[0]; rq[3] = t1[1];
+            }
             unsigned d[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -224,9 +235,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f8_kernel(const ConvA
                 float v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = acc[i][j][4 * g + q] * es[q] + bs[q];
-                if (has_res && mok && nok) {
+                if (has_res) {
                     float rv[4];
-                    unpack4_e4m3(*reinterpret_cast<const unsigned*>(resb + rrow + n), rv);
+                    unpack4_e4m3(rq[g], rv);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] += rv[q] * rs;
                 }
@@ -275,7 +286,7 @@ bool ConvF8Eligible(const ConvArgs& a, int tile) {
     if ((a.in.c & 15) || (a.in.sw & 15) || (a.in.sh & 15) || (a.in.sn & 15) || (reinterpret_cast<uintptr_t>(a.in.p) & 15)) return false;
     if ((a.out.c & 15) || (a.out.sw & 15) || (reinterpret_cast<uintptr_t>(a.out.p) & 15)) return false;
     if ((reinterpret_cast<uintptr_t>(a.w8) & 15) || (reinterpret_cast<uintptr_t>(a.escale) & 15) || (a.bias && (reinterpret_cast<uintptr_t>(a.bias) & 15))) return false;
-    if (a.res.p && (!a.res.f8 || a.res.sc != 1 || (a.res.sw & 3) || (reinterpret_cast<uintptr_t>(a.res.p) & 3) || a.res.n != a.out.n || a.res.h != a.out.h ||
+    if (a.res.p && (!a.res.f8 || a.res.sc != 1 || (a.res.sw & 15) || (reinterpret_cast<uintptr_t>(a.res.p) & 15) || a.res.n != a.out.n || a.res.h != a.out.h ||
                     a.res.w != a.out.w || a.res.c != a.out.c))
         return false;
     const int64_t in_span = int64_t(a.in.n - 1) * a.in.sn + int64_t(a.in.h - 1) * a.in.sh + int64_t(a.in.w - 1) * a.in.sw + a.in.c;
