@@ -647,7 +647,7 @@ void DeviceModel::Autotune(PlanInstance& pi, size_t nsteps, bool allow_search) {
                 for (size_t q = 0; q < s.parts.size(); ++q) { s.parts[q].algo = tmp.plan.steps[q].algo; s.parts[q].tile = tmp.plan.steps[q].tile; s.parts[q].splitk = tmp.plan.steps[q].splitk; }
                 const Step& p3 = s.parts[0];
                 std::vector<int64_t> keyf = {s.out.n * s.out.h * s.out.w, s.out.c, s.in.c, 1, 1, 1, 1, 0, 0, s.in.h, s.in.w, s.in.pitch, s.out.pitch, 0, int64_t(ConvAlgo::DenseFused),
-                                             s.pre_scale_off >= 0, s.bias_off >= 0, p3.in.c, p3.in.pitch, s.tile};
+                                             s.pre_scale_off >= 0, s.bias_off >= 0, p3.in.c, p3.in.pitch};
                 int choice = -1;
                 {
                     std::lock_guard<std::mutex> g(w_->tune_mu);
@@ -671,16 +671,27 @@ void DeviceModel::Autotune(PlanInstance& pi, size_t nsteps, bool allow_search) {
                         }
                         return best_ms;
                     };
-                    const float t_fused = time_it(s);
-                    Step split = s;
-                    split.tile = 0;
-                    const float t_split = time_it(split);
-                    choice = t_fused <= t_split ? 1 : 0;
+                    float best_t = 1e30f;
+                    choice = 0;
+                    for (int t = 0; t <= 3; ++t) {         // 0 = the two plain launches; 1, 2, 3 = fused tile variants
+                        Step trial = s;
+                        trial.tile = t;
+                        if (t > 0) {
+                            ConvArgs a1 = MakeConvArgs(pi, trial);
+                            FusedArgs f;
+                            f.in3 = make_arg(pi, p3.in);
+                            f.out3 = make_arg(pi, p3.out);
+                            f.wfrag3 = w_->d_weights_frag && p3.w_off >= 0 ? w_->d_weights_frag + p3.w_off : nullptr;
+                            if (!ConvDenseFusedEligible(a1, f, t)) continue;
+                        }
+                        const float ms = time_it(trial);
+                        if (ms < best_t) { best_t = ms; choice = t; }
+                    }
                     std::lock_guard<std::mutex> g(w_->tune_mu);
                     w_->tune_cache[keyf] = {choice, 1};
                     w_->tune_dirty = true;
                 }
-                if (choice == 0) s.tile = 0;           // tile 0: ConvDenseFusedEligible declines, the parts run
+                if (choice >= 0) s.tile = choice;          // tile 0: ConvDenseFusedEligible declines, the parts run
                 continue;
             }
             const Step planned = s;                    // the planner's default, kept when nothing better is known

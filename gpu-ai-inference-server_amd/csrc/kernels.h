@@ -122,8 +122,9 @@ bool ConvStemEligible(const ConvArgs& a);
 hipError_t LaunchConvStem(const ConvArgs& a, hipStream_t stream);
 hipError_t InitKernelsStem();
 // Fused dense-layer step (fp32): 3x3 growth conv of layer L + 1x1 bottleneck conv of layer L+1 per 16*pb-pixel tile, one launch.
-bool ConvDenseFusedEligible(const ConvArgs& a, const FusedArgs& f, int pb);
-hipError_t LaunchConvDenseFused(const ConvArgs& a, const FusedArgs& f, int pb, hipStream_t stream);
+// tile: 1 / 2 = 16-pixel blocks per workgroup; 3 = 16-pixel tiles, two workgroups per CU (<= 128 VGPRs, <= 80 KB LDS)
+bool ConvDenseFusedEligible(const ConvArgs& a, const FusedArgs& f, int tile);
+hipError_t LaunchConvDenseFused(const ConvArgs& a, const FusedArgs& f, int tile, hipStream_t stream);
 hipError_t InitKernelsFused();
 // fp8 precision mode (kernels_f8.hip): implicit GEMM on v_mfma_f32_32x32x16_fp8_fp8 over e4m3 NHWC activations and e4m3 weights,
 // fp32 accumulate, per-channel rescale + bias + e4m3 shortcut + ReLU + re-quantisation in the epilogue.  Tiles 0..6 of kIgemmTiles.

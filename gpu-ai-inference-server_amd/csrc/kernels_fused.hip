@@ -30,8 +30,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // PB: 16-pixel blocks per workgroup.  8 waves.  1x1: Cout == 128 (16 per wave).  3x3: stride 1, pad 1, Cout == 32, 9 * Cin3 / 16 <= 72 chunks.
-template <int PB, bool PRE>
-__global__ __launch_bounds__(512) void conv_dense_fused_kernel(const ConvArgs a, const FusedArgs f, const int part_off) {
+// OCC2: a variant meant to run TWO workgroups per CU (16-pixel tiles, <= 128 VGPRs, <= 80 KB of LDS): the old-channel loads are issued only
+// after the 3x3's MFMAs (their registers would otherwise overlap the 3x3's weight fragments); the latency this exposes is what the
+// second workgroup on the CU fills.
+template <int PB, bool PRE, bool OCC2>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC2 ? 4 : 2, OCC2 ? 4 : 2)))
+void conv_dense_fused_kernel(const ConvArgs a, const FusedArgs f, const int part_off) {
     constexpr int WAVES = 8, NT = 64 * WAVES, PX = 16 * PB, D = 8, MAXC3 = 9, TN3 = 2, PP = 32 + 4;
     constexpr int MAXS = PB == 1 ? 8 : 16;             // staging slots per thread for the old channels: PX * (K - 32) / 4 <= MAXS * NT
     constexpr unsigned OOB = 0x80000000u;
@@ -87,12 +91,15 @@ __global__ __launch_bounds__(512) void conv_dense_fused_kernel(const ConvArgs a,
     const int xrow0 = tid / c4n, xc4 = tid - xrow0 * c4n;
     const bool xact = xrow0 < rpp;                     // NT - rpp * c4n threads sit this phase out
     u32x4 xv[MAXS];
+    auto load_old_channels = [&]() {
 #pragma unroll
-    for (int u = 0; u < MAXS; ++u) {
-        const int row = xrow0 + u * rpp;
-        const int p = m0 + row;
-        xv[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (xact && row < PX && p < M && !(a.debug & 8)) ? unsigned(p * ipitch + xc4 * 4) * 4u : OOB, 0, 0);
-    }
+        for (int u = 0; u < MAXS; ++u) {
+            const int row = xrow0 + u * rpp;
+            const int p = m0 + row;
+            xv[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (xact && row < PX && p < M && !(a.debug & 8)) ? unsigned(p * ipitch + xc4 * 4) * 4u : OOB, 0, 0);
+        }
+    };
+    if constexpr (!OCC2) load_old_channels();
     f32x4 xsc = {1.f, 1.f, 1.f, 1.f}, xsf = {0.f, 0.f, 0.f, 0.f};
     f32x2 fsc = {1.f, 1.f}, fsf = {0.f, 0.f}, fb3 = {0.f, 0.f};
     const int fc2 = (tid & 15) * 2;                    // this thread's channel pair of the fresh 32 (phase i)
@@ -156,6 +163,8 @@ __global__ __launch_bounds__(512) void conv_dense_fused_kernel(const ConvArgs a,
             }
         }
     }
+
+    if constexpr (OCC2) load_old_channels();
 
     // ---- (f) prime the 1x1's weight ring (its latency hides behind the reduction and the staging below) ----
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wfrag), 0, 128 * K * 4, 0x00020000);
@@ -300,8 +309,11 @@ static size_t fused_lds_bytes(const ConvArgs& a, const FusedArgs& f, int pb, int
 
 static bool dense(const TensorArg& t) { return t.sc == 1 && t.sh == t.w * t.sw && t.sn == t.h * t.sh; }
 
-bool ConvDenseFusedEligible(const ConvArgs& a, const FusedArgs& f, int pb) {
-    if (pb != 1 && pb != 2) return false;
+// tile: 1 / 2 = 16-pixel blocks per workgroup (one workgroup per CU); 3 = 16-pixel tiles in the two-workgroups-per-CU variant
+bool ConvDenseFusedEligible(const ConvArgs& a, const FusedArgs& f, int tile) {
+    if (tile < 1 || tile > 3) return false;
+    const int pb = tile == 3 ? 1 : tile;
+    if (tile == 3 && fused_lds_bytes(a, f, 1) > size_t(80) * 1024) return false;
     if (a.in.f16 || a.out.f16 || a.in.f8 || a.out.f8 || f.in3.f16 || f.out3.f16 || f.in3.f8 || f.out3.f8) return false;
     if (a.wfrag == nullptr || f.wfrag3 == nullptr || a.res.p != nullptr) return false;
     if (a.kh != 1 || a.kw != 1 || a.sh != 1 || a.sw != 1 || a.pt != 0 || a.pl != 0) return false;
@@ -333,8 +345,10 @@ bool ConvDenseFusedEligible(const ConvArgs& a, const FusedArgs& f, int pb) {
     return fused_lds_bytes(a, f, pb) <= size_t(160) * 1024;
 }
 
-hipError_t LaunchConvDenseFused(const ConvArgs& a_in, const FusedArgs& f, int pb, hipStream_t stream) {
-    if (!ConvDenseFusedEligible(a_in, f, pb)) return hipErrorInvalidValue;
+hipError_t LaunchConvDenseFused(const ConvArgs& a_in, const FusedArgs& f, int tile, hipStream_t stream) {
+    if (!ConvDenseFusedEligible(a_in, f, tile)) return hipErrorInvalidValue;
+    const bool occ2 = tile == 3;
+    const int pb = occ2 ? 1 : tile;
     ConvArgs a = a_in;
     static const int dbg = [] { const char* e = std::getenv("IE_DEBUG_ABLATE"); return e ? std::atoi(e) : 0; }();
     a.debug = dbg;      // timing-only ablations (wrong results): 1 no 3x3 MFMAs, 2 no 1x1 loop, 4 no 3x3 weight loads, 8 no old-channel loads, 16 no 1x1 weight loads
@@ -342,22 +356,26 @@ hipError_t LaunchConvDenseFused(const ConvArgs& a_in, const FusedArgs& f, int pb
     const dim3 grid(unsigned((M + 16 * pb - 1) / (16 * pb)));
     int part_off = 0;
     const size_t lds = fused_lds_bytes(a, f, pb, &part_off);
-    if (pb == 1) {
-        if (a.pre_scale) conv_dense_fused_kernel<1, true><<<grid, dim3(512), lds, stream>>>(a, f, part_off);
-        else conv_dense_fused_kernel<1, false><<<grid, dim3(512), lds, stream>>>(a, f, part_off);
+    if (occ2) {
+        if (a.pre_scale) conv_dense_fused_kernel<1, true, true><<<grid, dim3(512), lds, stream>>>(a, f, part_off);
+        else conv_dense_fused_kernel<1, false, true><<<grid, dim3(512), lds, stream>>>(a, f, part_off);
+    } else if (pb == 1) {
+        if (a.pre_scale) conv_dense_fused_kernel<1, true, false><<<grid, dim3(512), lds, stream>>>(a, f, part_off);
+        else conv_dense_fused_kernel<1, false, false><<<grid, dim3(512), lds, stream>>>(a, f, part_off);
     } else {
-        if (a.pre_scale) conv_dense_fused_kernel<2, true><<<grid, dim3(512), lds, stream>>>(a, f, part_off);
-        else conv_dense_fused_kernel<2, false><<<grid, dim3(512), lds, stream>>>(a, f, part_off);
+        if (a.pre_scale) conv_dense_fused_kernel<2, true, false><<<grid, dim3(512), lds, stream>>>(a, f, part_off);
+        else conv_dense_fused_kernel<2, false, false><<<grid, dim3(512), lds, stream>>>(a, f, part_off);
     }
     return hipGetLastError();
 }
 
 hipError_t InitKernelsFused() {
     hipError_t e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dense_fused_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dense_fused_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dense_fused_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dense_fused_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define IE_FUSED_ATTR(PB, PRE, OCC)                                                                                                                                 \
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dense_fused_kernel<PB, PRE, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    IE_FUSED_ATTR(1, true, false) IE_FUSED_ATTR(1, false, false) IE_FUSED_ATTR(2, true, false) IE_FUSED_ATTR(2, false, false) IE_FUSED_ATTR(1, true, true) IE_FUSED_ATTR(1, false, true)
+#undef IE_FUSED_ATTR
+    return hipSuccess;
 }
 
 }  // namespace ie

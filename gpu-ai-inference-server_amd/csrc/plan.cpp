@@ -1146,7 +1146,8 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                        s3.in.pitch % 4 == 0 && s3.in.c_off % 4 == 0 && s1.in.pitch % 4 == 0 && s1.in.c_off % 4 == 0 && s1.out.pitch % 4 == 0 && s1.out.c_off % 4 == 0;
                 if (fuse) {
                     int pb = M <= 2048 ? 1 : 2;
-                    if (const char* e = std::getenv("IE_FUSE_PB")) { const int v = std::atoi(e); if (v == 1 || v == 2) pb = v; }
+                    int ftile = 0;
+                    if (const char* e = std::getenv("IE_FUSE_PB")) { const int v = std::atoi(e); if (v == 1 || v == 2) pb = v; if (v == 3) { pb = 1; ftile = 3; } }
                     const int64_t px = 16 * pb;
                     const int64_t win = (px + 2 * s3.in.w + 2) * (s3.in.c + 4) * 4, part = 4 * px * 36 * 4;
                     const int64_t c4n = (s1.in.c - 32) / 4, rpp = c4n > 0 && c4n <= 512 ? 512 / c4n : 0;
@@ -1156,7 +1157,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                     if (fuse) {
                         Step f = s1;
                         f.algo = ConvAlgo::DenseFused;
-                        f.tile = pb;
+                        f.tile = ftile ? ftile : pb;
                         f.splitk = 1;
                         f.name = s3.name + " | " + s1.name;
                         f.flops = s3.flops + s1.flops;

@@ -1509,8 +1509,9 @@ def test_fp8_rejects_graphs_it_cannot_run(densenet_repo):
     _run_with_env(dict(IE_PRECISION="fp8"), go)
 
 
+@pytest.mark.parametrize("fuse_tile", ["", "3"])
 @pytest.mark.parametrize("batch,image,blocks", [(2, 64, (3, 4)), (5, 56, (2, 3, 2)), (32, 28, (4,)), (8, 112, (3, 2)), (3, 104, (2, 2))])
-def test_fused_dense_layer_kernel(tmp_path, batch, image, blocks):
+def test_fused_dense_layer_kernel(tmp_path, batch, image, blocks, fuse_tile):
     """conv_dense_fused_kernel (3x3 growth conv of layer L + 1x1 bottleneck conv of layer L+1 in one launch) on DenseNet-shaped
     graphs with growth 32 / bottleneck 128: both pixel-tile sizes, image widths 16 / 14 / 8 / 7 / 4, ragged last tiles, against the
     float64 oracle; and bit-for-bit determinism plus agreement with the unfused plan (IE_NO_DENSE_FUSE=1)."""
@@ -1530,7 +1531,10 @@ def test_fused_dense_layer_kernel(tmp_path, batch, image, blocks):
             m.Destroy()
         np.testing.assert_array_equal(y, y2)
         return plan, y
-    plan, y = _run_with_env(dict(IE_AUTOTUNE="0"), go)
+    env = dict(IE_AUTOTUNE="0")
+    if fuse_tile:
+        env["IE_FUSE_PB"] = fuse_tile          # 3 = the two-workgroups-per-CU variant of the 16-pixel tile
+    plan, y = _run_with_env(env, go)
     nf = [s for s in plan["steps"] if s.get("algo") == "dense_fused"]
     assert len(nf) >= sum(b - 1 for b in blocks) - 2, (len(nf), blocks)
     plan0, y0 = _run_with_env(dict(IE_AUTOTUNE="0", IE_NO_DENSE_FUSE="1"), go)
