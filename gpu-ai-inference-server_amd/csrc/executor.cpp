@@ -673,7 +673,7 @@ void DeviceModel::Autotune(PlanInstance& pi, size_t nsteps, bool allow_search) {
                     };
                     float best_t = 1e30f;
                     choice = 0;
-                    for (int t = 0; t <= 3; ++t) {         // 0 = the two plain launches; 1, 2, 3 = fused tile variants
+                    for (int t = 0; t <= 5; ++t) {         // 0 = the two plain launches; 1 .. 5 = fused tile variants (kernels_fused.hip)
                         Step trial = s;
                         trial.tile = t;
                         if (t > 0) {
@@ -1108,7 +1108,7 @@ static std::string kernel_label(const Step& s) {
     switch (s.kind) {
         case StepKind::Conv:
             if (s.algo == ConvAlgo::Naive) return "conv_naive_kernel";
-            if (s.algo == ConvAlgo::DenseFused) return "conv_dense_fused_kernel<pb" + std::to_string(s.tile) + ">";
+            if (s.algo == ConvAlgo::DenseFused) return (s.tile >= 4 ? "conv_dense_fused_ws_kernel<t" : "conv_dense_fused_kernel<t") + std::to_string(s.tile) + ">";
             if (s.algo == ConvAlgo::IgemmF8)
                 return "conv_igemm_f8_kernel<" + std::to_string(kIgemmTiles[s.tile].bm) + "x" + std::to_string(kIgemmTiles[s.tile].bn) + ">";
             if (s.algo == ConvAlgo::Direct) {       // one launcher family, three kernels (kernels_direct.hip): report the one that runs

@@ -122,7 +122,8 @@ bool ConvStemEligible(const ConvArgs& a);
 hipError_t LaunchConvStem(const ConvArgs& a, hipStream_t stream);
 hipError_t InitKernelsStem();
 // Fused dense-layer step (fp32): 3x3 growth conv of layer L + 1x1 bottleneck conv of layer L+1 per 16*pb-pixel tile, one launch.
-// tile: 1 / 2 = 16-pixel blocks per workgroup; 3 = 16-pixel tiles, two workgroups per CU (<= 128 VGPRs, <= 80 KB LDS)
+// tile: 1 / 2 = 16-pixel blocks per workgroup; 3 = 16-pixel tiles, two workgroups per CU (<= 128 VGPRs, <= 80 KB LDS);
+// 4 / 5 = wave-specialised variant (3x3 and 1x1 run concurrently on different waves), 16 / 32 pixels
 bool ConvDenseFusedEligible(const ConvArgs& a, const FusedArgs& f, int tile);
 hipError_t LaunchConvDenseFused(const ConvArgs& a, const FusedArgs& f, int tile, hipStream_t stream);
 hipError_t InitKernelsFused();

@@ -1147,7 +1147,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                 if (fuse) {
                     int pb = M <= 2048 ? 1 : 2;
                     int ftile = 0;
-                    if (const char* e = std::getenv("IE_FUSE_PB")) { const int v = std::atoi(e); if (v == 1 || v == 2) pb = v; if (v == 3) { pb = 1; ftile = 3; } }
+                    if (const char* e = std::getenv("IE_FUSE_PB")) { const int v = std::atoi(e); if (v == 1 || v == 2) pb = v; if (v == 3) { pb = 1; ftile = 3; } if (v == 4 || v == 5) { pb = v - 3; ftile = v; } }
                     const int64_t px = 16 * pb;
                     const int64_t win = (px + 2 * s3.in.w + 2) * (s3.in.c + 4) * 4, part = 4 * px * 36 * 4;
                     const int64_t c4n = (s1.in.c - 32) / 4, rpp = c4n > 0 && c4n <= 512 ? 512 / c4n : 0;

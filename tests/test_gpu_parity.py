@@ -1509,7 +1509,7 @@ def test_fp8_rejects_graphs_it_cannot_run(densenet_repo):
     _run_with_env(dict(IE_PRECISION="fp8"), go)
 
 
-@pytest.mark.parametrize("fuse_tile", ["", "3"])
+@pytest.mark.parametrize("fuse_tile", ["", "3", "4", "5"])
 @pytest.mark.parametrize("batch,image,blocks", [(2, 64, (3, 4)), (5, 56, (2, 3, 2)), (32, 28, (4,)), (8, 112, (3, 2)), (3, 104, (2, 2))])
 def test_fused_dense_layer_kernel(tmp_path, batch, image, blocks, fuse_tile):
     """conv_dense_fused_kernel (3x3 growth conv of layer L + 1x1 bottleneck conv of layer L+1 in one launch) on DenseNet-shaped
@@ -1533,7 +1533,7 @@ def test_fused_dense_layer_kernel(tmp_path, batch, image, blocks, fuse_tile):
         return plan, y
     env = dict(IE_AUTOTUNE="0")
     if fuse_tile:
-        env["IE_FUSE_PB"] = fuse_tile          # 3 = the two-workgroups-per-CU variant of the 16-pixel tile
+        env["IE_FUSE_PB"] = fuse_tile          # 3 = two-workgroups-per-CU variant of the 16-pixel tile; 4, 5 = wave-specialised variants
     plan, y = _run_with_env(env, go)
     nf = [s for s in plan["steps"] if s.get("algo") == "dense_fused"]
     assert len(nf) >= sum(b - 1 for b in blocks) - 2, (len(nf), blocks)
