@@ -321,8 +321,11 @@ __global__ __launch_bounds__(512) void conv_dense_fused_ws_kernel(const ConvArgs
 
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, gk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool conv3 = wave < CW;                      // wave-uniform role
-    const int wr = conv3 ? wave : wave - CW;           // index inside the role
+    // role by wave half (waves i and i + 4 share a SIMD: measured, the parity split -- a.debug bit 32 -- is 8 % slower), so every SIMD hosts
+    // one wave of each role
+    const bool by_half = (a.debug & 32) == 0;
+    const bool conv3 = by_half ? wave < CW : (wave & 1) == 0;      // wave-uniform role
+    const int wr = by_half ? (conv3 ? wave : wave - CW) : (wave >> 1);   // index inside the role
     const int H = a.in.h, W = a.in.w;
     const int M = a.in.n * H * W;
     const int m0 = blockIdx.x * PX;
@@ -464,8 +467,7 @@ __global__ __launch_bounds__(512) void conv_dense_fused_ws_kernel(const ConvArgs
         for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
             for (int j = 0; j < TN3; ++j) *reinterpret_cast<f32x4*>(sPart + (wr * PX + pb * 16 + r) * PP + j * 16 + 4 * gk) = acc3[pb][j];
-        __atomic_thread_fence(__ATOMIC_RELEASE);       // ds writes retired before the arrival is visible
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // ds writes retired before the arrival is visible (workgroup scope: LDS only, no cache write-back)
         if (lane == 0) __hip_atomic_fetch_add(&sCnt[0], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         while (__hip_atomic_load(&sCnt[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < CW) __builtin_amdgcn_s_sleep(1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -634,12 +636,15 @@ hipError_t LaunchConvDenseFused(const ConvArgs& a_in, const FusedArgs& f, int ti
         const dim3 gridw(unsigned((Mw + 16 * pb - 1) / (16 * pb)));
         int win_off = 0, poff = 0;
         const size_t ldsw = fused_ws_lds_bytes(a_in, f, pb, &win_off, &poff);
+        ConvArgs aw = a_in;
+        static const int dbgw = [] { const char* e = std::getenv("IE_DEBUG_ABLATE"); return e ? std::atoi(e) : 0; }();
+        aw.debug = dbgw;
         if (pb == 1) {
-            if (a_in.pre_scale) conv_dense_fused_ws_kernel<1, true><<<gridw, dim3(512), ldsw, stream>>>(a_in, f, win_off, poff);
-            else conv_dense_fused_ws_kernel<1, false><<<gridw, dim3(512), ldsw, stream>>>(a_in, f, win_off, poff);
+            if (aw.pre_scale) conv_dense_fused_ws_kernel<1, true><<<gridw, dim3(512), ldsw, stream>>>(aw, f, win_off, poff);
+            else conv_dense_fused_ws_kernel<1, false><<<gridw, dim3(512), ldsw, stream>>>(aw, f, win_off, poff);
         } else {
-            if (a_in.pre_scale) conv_dense_fused_ws_kernel<2, true><<<gridw, dim3(512), ldsw, stream>>>(a_in, f, win_off, poff);
-            else conv_dense_fused_ws_kernel<2, false><<<gridw, dim3(512), ldsw, stream>>>(a_in, f, win_off, poff);
+            if (aw.pre_scale) conv_dense_fused_ws_kernel<2, true><<<gridw, dim3(512), ldsw, stream>>>(aw, f, win_off, poff);
+            else conv_dense_fused_ws_kernel<2, false><<<gridw, dim3(512), ldsw, stream>>>(aw, f, win_off, poff);
         }
         return hipGetLastError();
     }

@@ -10,8 +10,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export IE_TUNE_CACHE=$OUT/tune_cache.txt
 [ -n "$IE_PROFILE_EAGER" ] && export IE_DISABLE_GRAPH=1
-python3 $R/bench.py --steps 50 --warmup 10 > $OUT/bench.json 2> $OUT/bench.err || exit 1
-echo "bench done"
+ROUND=$(basename $OUT)
 python3 $R/scripts/profile_steps.py 32 > $OUT/steps_b32.txt 2>&1
 IE_PRECISION=fp16 python3 $R/scripts/profile_steps.py 128 > $OUT/steps_f16_b128.txt 2>&1
 IE_PRECISION=fp8 python3 $R/scripts/profile_steps.py 256 resnet50 > $OUT/steps_resnet50_f8_b256.txt 2>&1
@@ -33,4 +32,8 @@ for CFG in "${CONFIGS[@]}"; do
   python3 $R/scripts/make_traffic.py $OUT $SUF > $OUT/traffic$SUF.json
   echo "config $NAME done"
 done
+# the bench line last, with this run's traffic files already in profiles/<round>/ so that its roofline.traffic comes from the same session
+mkdir -p $R/profiles/$ROUND && cp $OUT/traffic*.json $R/profiles/$ROUND/
+python3 $R/bench.py --steps 50 --warmup 10 > $OUT/bench.json 2> $OUT/bench.err || exit 1
+echo "bench done"
 ls -la $OUT
