@@ -188,7 +188,7 @@ def measure(B, models, sharding, *, model_name, dtype, Bsz, steps, warmup, rank,
             "p50_ms": round(p50, 4),
         }
         # ---- roofline of the dominant kernel family, HIP events on the model's stream --------------------------
-        prof = B.Profile(model, 5)
+        prof = B.Profile(model, 9)
         fam = {}
         for p in prof:
             k = p["kernel"].split("<")[0]

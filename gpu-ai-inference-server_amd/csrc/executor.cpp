@@ -1169,14 +1169,21 @@ std::vector<StepTiming> DeviceModel::Profile(PlanInstance& pi, int iters) {
     try {
         RunSteps(pi, 0, ns, nullptr);   // warm
         check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+        // per step the MEDIAN over the passes: one disturbed pass (clock ramp, a neighbour's burst) must not colour a family's figure
+        std::vector<std::vector<float>> samples(ns);
         for (int it = 0; it < iters; ++it) {
             RunSteps(pi, 0, ns, &ev);
             check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
             for (size_t i = 0; i < ns; ++i) {
                 float ms = 0;
                 check(hipEventElapsedTime(&ms, ev[i], ev[i + 1]), "hipEventElapsedTime");
-                out[i].ms += ms / float(iters);
+                samples[i].push_back(ms);
             }
+        }
+        for (size_t i = 0; i < ns; ++i) {
+            std::sort(samples[i].begin(), samples[i].end());
+            const size_t n = samples[i].size();
+            out[i].ms = n == 0 ? 0.0 : (n % 2 ? samples[i][n / 2] : 0.5 * (samples[i][n / 2 - 1] + samples[i][n / 2]));
         }
     } catch (...) {
         for (auto& e : ev) (void)hipEventDestroy(e);
