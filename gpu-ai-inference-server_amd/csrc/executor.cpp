@@ -83,6 +83,7 @@ DeviceWeights::~DeviceWeights() {
     if (d_weights_frag) (void)hipFree(d_weights_frag);
     if (d_weights8) (void)hipFree(d_weights8);
     if (d_f8_aux) (void)hipFree(d_f8_aux);
+    if (d_weights_wino) (void)hipFree(d_weights_wino);
 }
 
 namespace {
@@ -90,7 +91,7 @@ namespace {
 std::string tune_file_header() {
     std::ostringstream o;
     o << kTuneFileTag << ' ' << kNumIgemmTiles << ' ' << kNumConvRasterTiles << ' ' << kNumConvWs32Tiles << ' ' << kNumConvWs3Tiles << ' '
-      << kNumConvDirectTiles;
+      << kNumConvDirectTiles << ' ' << kNumConvWinoTiles;
     return o.str();
 }
 
@@ -113,7 +114,7 @@ void load_tune_file(const std::string& path, std::map<std::vector<int64_t>, std:
         }
         int t = -1, sp = 0;
         if (ok && (is >> t >> sp) && ((t >= 0 && t < kNumIgemmTiles) || (t >= 100 && t < 100 + kNumConvRasterTiles) || (t >= 200 && t < 200 + kNumConvWs32Tiles) ||
-                                       (t >= 300 && t < 300 + kNumConvWs3Tiles) || (t >= 400 && t < 400 + kNumConvDirectTiles)) &&
+                                       (t >= 300 && t < 300 + kNumConvWs3Tiles) || (t >= 400 && t < 400 + kNumConvDirectTiles) || (t >= 500 && t < 500 + kNumConvWinoTiles)) &&
             sp >= 1 && sp <= 64 && key.size() >= 17)
             cache[key] = {t, sp};
     }
@@ -137,6 +138,7 @@ DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id, 
         if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsDirect();
         if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsF8();
         if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsFused();
+        if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsWino();
     });
     check(g_kernels_err, "InitKernels");
     if (opt.share) {
@@ -253,6 +255,18 @@ void DeviceModel::BuildInstance(PlanInstance& pi, const std::vector<std::vector<
                     check(hipMalloc(reinterpret_cast<void**>(&w_->d_weights_frag), w_->weight_floats * sizeof(float)), "hipMalloc(weights_frag)");
                     w_->device_bytes += w_->weight_floats * sizeof(float);
                 }
+                // Winograd-transformed weights for the 3x3 / s1 / p1 convs with 32 output channels (kernels_wino.hip)
+                int64_t utot = 0;
+                for (const Step& st : pi.plan.steps)
+                    if (st.parts.empty() && st.kind == StepKind::Conv && st.w_off >= 0 && st.kh == 3 && st.kw == 3 && st.sh == 1 && st.sw == 1 && st.pt == 1 && st.pl == 1 &&
+                        st.out.c == 32 && st.in.c % 16 == 0 && !st.in.nchw) {
+                        w_->wino_regions.push_back({st.w_off, utot, 32, int(st.in.c)});
+                        utot += int64_t(16) * 32 * st.in.c;
+                    }
+                if (utot > 0) {
+                    check(hipMalloc(reinterpret_cast<void**>(&w_->d_weights_wino), size_t(utot) * sizeof(float)), "hipMalloc(weights_wino)");
+                    w_->device_bytes += size_t(utot) * sizeof(float);
+                }
             }
             if (w_->uploaded) WeightsArrived();
         } else if (pi.plan.weights.size() != w_->weight_floats) {
@@ -355,6 +369,12 @@ PlanInstance& DeviceModel::Prepare(const std::vector<std::vector<int64_t>>& shap
 // Rebuilds what is derived from the fp32 weight blob: the half mirror (fp16 mode) or the fragment-major conv weights (fp32 mode).
 void DeviceModel::WeightsArrived() {
     w_->uploaded = true;
+    if (w_->d_weights_wino) {
+        check(hipSetDevice(device_), "hipSetDevice");
+        for (const auto& wr : w_->wino_regions)
+            check(LaunchWinogradWeights(w_->d_weights + wr.w_off, w_->d_weights_wino + wr.u_off, wr.cout, wr.cin, stream_), "winograd_weights");
+        check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+    }
     if (!w_->d_weights16 && !w_->d_weights_frag) return;
     check(hipSetDevice(device_), "hipSetDevice");
     w_->f8_ready = false;
@@ -696,7 +716,7 @@ void DeviceModel::Autotune(PlanInstance& pi, size_t nsteps, bool allow_search) {
             }
             const Step planned = s;                    // the planner's default, kept when nothing better is known
             // the planner's default may already name a specialised kernel: the search starts from the tiled implicit GEMM either way
-            if (s.algo == ConvAlgo::Ws1x1 || s.algo == ConvAlgo::Ws3x3 || s.algo == ConvAlgo::Direct || s.algo == ConvAlgo::Raster3x3) {
+            if (s.algo == ConvAlgo::Ws1x1 || s.algo == ConvAlgo::Ws3x3 || s.algo == ConvAlgo::Direct || s.algo == ConvAlgo::Raster3x3 || s.algo == ConvAlgo::Wino3x3) {
                 s.algo = ConvAlgo::IgemmVec;
                 s.tile = s.base_tile;
                 s.splitk = 1;
@@ -747,7 +767,8 @@ void DeviceModel::Autotune(PlanInstance& pi, size_t nsteps, bool allow_search) {
             if (s.in.f16 || s.out.f16) { key.push_back(s.in.f16); key.push_back(s.out.f16); }   // fp32 signatures keep 17 entries
             if (s.has_in2) key.push_back(1);              // a fused residual changes which kernels apply (18 / 20 entries)
             auto apply = [&](int enc_tile, int sp) {     // tile >= 100 encodes the raster kernel, >= 200 the weights-stationary 1x1
-                if (enc_tile >= 400) { s.algo = ConvAlgo::Direct; s.tile = enc_tile - 400; }
+                if (enc_tile >= 500) { s.algo = ConvAlgo::Wino3x3; s.tile = enc_tile - 500; }
+                else if (enc_tile >= 400) { s.algo = ConvAlgo::Direct; s.tile = enc_tile - 400; }
                 else if (enc_tile >= 300) { s.algo = ConvAlgo::Ws3x3; s.tile = enc_tile - 300; }
                 else if (enc_tile >= 200) { s.algo = ConvAlgo::Ws1x1; s.tile = enc_tile - 200; }
                 else if (enc_tile >= 100) { s.algo = ConvAlgo::Raster3x3; s.tile = enc_tile - 100; }
@@ -778,6 +799,8 @@ void DeviceModel::Autotune(PlanInstance& pi, size_t nsteps, bool allow_search) {
                             const IgemmTile& T = kIgemmTiles[choice.first];
                             const int64_t wgs = ((M + T.bm - 1) / T.bm) * ((N + T.bn - 1) / T.bn);
                             if (KT / sp < 2 || int64_t(sp) * wgs * T.bm * T.bn > pi.workspace_floats || wgs > kNumCounters || wgs * sp > 8192 || wgs >= 1024) sp = 1;
+                        } else if (choice.first >= 500) {
+                            sp = 1;
                         } else if (choice.first < 200) {
                             if (int64_t(sp) * (M + 256) * (N + 64) * 2 > pi.workspace_floats || (s.in.n * (s.in.h + 1) * (s.in.w + 1)) / 64 * sp > 16384) sp = 1;
                         } else sp = 1;
@@ -844,6 +867,21 @@ void DeviceModel::Autotune(PlanInstance& pi, size_t nsteps, bool allow_search) {
                         float ms = time_trial(trial);
                         if (ms < best) { best = ms; best_tile = 100 + t; best_split = sp; }
                     }
+                }
+            }
+            // Winograd F(2x2, 3x3): 2.25x fewer MACs for the 32-channel 3x3 convs on even-sized images
+            if (!s.in.f16 && !s.out.f16 && s.algo == ConvAlgo::IgemmVec && s.kh == 3 && s.kw == 3 && s.out.c == 32 && !s.has_in2) {
+                Step probe_step = s;
+                probe_step.algo = ConvAlgo::Wino3x3;
+                ConvArgs probe = MakeConvArgs(pi, probe_step);
+                for (int t = 0; t < kNumConvWinoTiles; ++t) {
+                    if (!ConvWinoEligible(probe, t)) continue;
+                    Step trial = s;
+                    trial.algo = ConvAlgo::Wino3x3;
+                    trial.tile = t;
+                    trial.splitk = 1;
+                    float ms = time_trial(trial);
+                    if (ms < best) { best = ms; best_tile = 500 + t; best_split = 1; }
                 }
             }
             // the kernels_direct.hip family (every variant checks its own pixel-count / shape limits): K split over the waves with
@@ -965,6 +1003,11 @@ ConvArgs DeviceModel::MakeConvArgs(const PlanInstance& pi, const Step& s) const 
     a.workspace_floats = pi.workspace_floats;
     a.counters = pi.counters;
     a.num_counters = pi.counters ? kNumCounters : 0;
+    if (s.algo == ConvAlgo::Wino3x3) {               // the Winograd kernel reads the transformed weights through `wfrag`
+        a.wfrag = nullptr;
+        for (const auto& wr : w_->wino_regions)
+            if (wr.w_off == s.w_off && w_->d_weights_wino) a.wfrag = w_->d_weights_wino + wr.u_off;
+    }
     if (s.out.f8 || s.in.f8) {       // fp8 mode: e4m3 weights, per-channel epilogue multipliers, tensor scales
         const DeviceWeights& W = *w_;
         auto scale_of = [&](int step) { return step >= 0 && size_t(step) < W.act_scale.size() && W.act_scale[size_t(step)] > 0.f ? W.act_scale[size_t(step)] : 1.f; };
@@ -1015,6 +1058,7 @@ void DeviceModel::LaunchStep(const PlanInstance& pi, const Step& s_in, hipStream
                     case ConvAlgo::Ws3x3: ok = ConvWs3Eligible(plain, s_in.tile); break;
                     case ConvAlgo::Direct: ok = ConvDirectEligible(plain, s_in.tile); break;
                     case ConvAlgo::Raster3x3: ok = ConvRasterEligible(plain, s_in.tile); break;
+                    case ConvAlgo::Wino3x3: ok = ConvWinoEligible(plain, s_in.tile); break;
                     case ConvAlgo::Stem: ok = ConvStemEligible(a); break;
                     default: break;
                 }
@@ -1047,6 +1091,7 @@ void DeviceModel::LaunchStep(const PlanInstance& pi, const Step& s_in, hipStream
             else if (s.algo == ConvAlgo::Ws1x1) check(LaunchConvWs1x1F32(a, s.tile, stream_), "conv1x1_ws_f32");
             else if (s.algo == ConvAlgo::Ws3x3) check(LaunchConvWs3x3F16(a, s.tile, stream_), "conv3x3_ws_f16");
             else if (s.algo == ConvAlgo::Stem) check(LaunchConvStem(a, stream_), "conv_stem");
+            else if (s.algo == ConvAlgo::Wino3x3) check(LaunchConvWino3x3(a, s.tile, stream_), "conv3x3_wino");
             else if (s.algo == ConvAlgo::Direct) check(LaunchConvDirect(a, s.tile, stream_), "conv_direct");
             else if (s.in.f16) check(LaunchConvIgemmF16(a, s.tile, s.splitk, stream_), "conv_igemm_f16");
             else check(LaunchConvIgemm(a, s.tile, s.algo == ConvAlgo::IgemmVec ? 1 : 0, s.splitk, stream_), "conv_igemm");
@@ -1119,6 +1164,7 @@ static std::string kernel_label(const Step& s) {
             if (s.algo == ConvAlgo::Stem) return s.out.f8 ? "conv_stem_kernel<f16,e4m3 out>" : (s.out.f16 ? "conv_stem_kernel<f16>" : "conv_stem_kernel<f32>");
             if (s.algo == ConvAlgo::Ws1x1) return std::string(s.in.f16 ? "conv1x1_ws_f16_kernel<t" : "conv1x1_ws_f32_kernel<t") + std::to_string(s.tile) + ">";
             if (s.algo == ConvAlgo::Ws3x3) return "conv3x3_ws_f16_kernel<t" + std::to_string(s.tile) + ">";
+            if (s.algo == ConvAlgo::Wino3x3) return "conv3x3_wino_kernel<t" + std::to_string(s.tile) + ">";
             if (s.algo == ConvAlgo::Raster3x3)
                 return "conv3x3_raster_kernel<t" + std::to_string(s.tile) + (s.splitk > 1 ? ",splitk" + std::to_string(s.splitk) : std::string()) + ">";
             return std::string(s.in.f16 ? "conv_igemm_f16_kernel<" : "conv_igemm_kernel<") + std::to_string(kIgemmTiles[s.tile].bm) + "x" +

@@ -43,6 +43,10 @@ struct DeviceWeights {
     std::vector<F8Conv> f8_convs;
     std::vector<float> act_scale;
     bool f8_ready = false;
+    // fp32 mode: Winograd-transformed weights U (16 x Cout x Cin floats per eligible 3x3 conv, fragment-major), own offsets
+    float* d_weights_wino = nullptr;
+    struct WinoRegion { int64_t w_off, u_off; int cout, cin; };
+    std::vector<WinoRegion> wino_regions;
     struct FragRegion { int64_t w_off; int cout, kk, cin; };
     std::vector<FragRegion> frag_regions;
     size_t weight_floats = 0;

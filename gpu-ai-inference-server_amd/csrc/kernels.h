@@ -121,6 +121,13 @@ hipError_t InitKernelsDirect();
 bool ConvStemEligible(const ConvArgs& a);
 hipError_t LaunchConvStem(const ConvArgs& a, hipStream_t stream);
 hipError_t InitKernelsStem();
+// Winograd F(2x2, 3x3) conv (kernels_wino.hip): fp32, 3x3 / stride 1 / pad 1, 32 output channels, even H and W; a.wfrag = the transformed
+// weights U (16 x Cout x Cin floats, fragment-major) built by LaunchWinogradWeights.  tile: 0..3 = output tiles per workgroup.
+constexpr int kNumConvWinoTiles = 4;
+bool ConvWinoEligible(const ConvArgs& a, int tile);
+hipError_t LaunchConvWino3x3(const ConvArgs& a, int tile, hipStream_t stream);
+hipError_t LaunchWinogradWeights(const float* w, float* u, int Cout, int Cin, hipStream_t stream);
+hipError_t InitKernelsWino();
 // Fused dense-layer step (fp32): 3x3 growth conv of layer L + 1x1 bottleneck conv of layer L+1 per 16*pb-pixel tile, one launch.
 // tile: 1 / 2 = 16-pixel blocks per workgroup; 3 = 16-pixel tiles, two workgroups per CU (<= 128 VGPRs, <= 80 KB LDS);
 // 4 / 5 = wave-specialised variant (3x3 and 1x1 run concurrently on different waves), 16 / 32 pixels

@@ -981,6 +981,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                            n.kh * n.kw <= 49;
                 };
                 const bool raster_ok = vec_ok && !s.out.f16 && is3x3 && !n.has_pre;
+                const bool wino_ok = raster_ok && N == 32 && s.in.c % 16 == 0 && s.in.h % 2 == 0 && s.in.w % 2 == 0 && n.res < 0 && s.out.pitch % 4 == 0 && s.out.c_off % 4 == 0;
                 // ---- default choice without the autotuner (IE_AUTOTUNE=0, or before Prepare() has timed anything): the kernels
                 //      the exhaustive search picks for DenseNet / ResNet shapes ----
                 if (s.algo == ConvAlgo::IgemmF8) {
@@ -1025,6 +1026,14 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                         if (direct_ok(t)) { s.algo = ConvAlgo::Direct; s.tile = t; }
                         else if (s.algo == ConvAlgo::Naive && (vec_ok || vec16_ok)) s.algo = ConvAlgo::IgemmVec;
                     }
+                    else if (f == "wino") {
+                        if (wino_ok) {
+                            s.algo = ConvAlgo::Wino3x3;
+                            s.tile = 0;
+                            if (const char* ft = std::getenv("IE_FORCE_TILE")) { int t = std::atoi(ft); if (t >= 0 && t < 4) s.tile = t; }
+                        } else if (s.algo == ConvAlgo::Naive)
+                            s.algo = (vec_ok || vec16_ok) ? ConvAlgo::IgemmVec : (K <= 2048 && !in16 ? ConvAlgo::IgemmScalar : ConvAlgo::Naive);
+                    }
                     else if (f == "raster") {
                         if (raster_ok) {
                             s.algo = ConvAlgo::Raster3x3;
@@ -1034,12 +1043,12 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                             s.algo = (vec_ok || vec16_ok) ? ConvAlgo::IgemmVec : (K <= 2048 && !in16 ? ConvAlgo::IgemmScalar : ConvAlgo::Naive);
                     }
                 }
-                if (const char* ft = (s.algo == ConvAlgo::Raster3x3 || s.algo == ConvAlgo::Ws1x1 || s.algo == ConvAlgo::Ws3x3 || s.algo == ConvAlgo::Stem || s.algo == ConvAlgo::Direct) ? nullptr
+                if (const char* ft = (s.algo == ConvAlgo::Raster3x3 || s.algo == ConvAlgo::Ws1x1 || s.algo == ConvAlgo::Ws3x3 || s.algo == ConvAlgo::Stem || s.algo == ConvAlgo::Direct || s.algo == ConvAlgo::Wino3x3) ? nullptr
                                                                                                                                           : std::getenv("IE_FORCE_TILE")) {
                     int t = std::atoi(ft);
                     if (t >= 0 && t < kNumIgemmTiles && (t < kNumIgemmBaseTiles || s.algo == ConvAlgo::IgemmVec) && !(in16 && kIgemmTiles[t].deep)) s.tile = t;
                 }
-                if (s.algo != ConvAlgo::IgemmVec && s.algo != ConvAlgo::Raster3x3 && s.algo != ConvAlgo::Ws1x1 && s.algo != ConvAlgo::Ws3x3 && s.algo != ConvAlgo::Direct && s.tile >= kNumIgemmBaseTiles)
+                if (s.algo != ConvAlgo::IgemmVec && s.algo != ConvAlgo::Raster3x3 && s.algo != ConvAlgo::Ws1x1 && s.algo != ConvAlgo::Ws3x3 && s.algo != ConvAlgo::Direct && s.algo != ConvAlgo::Wino3x3 && s.tile >= kNumIgemmBaseTiles)
                     s.tile = heuristic_tile;       // K-group tiles exist for the vector path only
                 if (s.algo == ConvAlgo::Raster3x3) {
                     if (const char* fs = std::getenv("IE_FORCE_SPLITK")) {
@@ -1047,7 +1056,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                         if (v >= 1 && v <= 64) s.splitk = v;
                     }
                     if (s.splitk > 1) plan.workspace_floats = std::max<int64_t>(plan.workspace_floats, int64_t(s.splitk) * M * N);
-                } else if (s.algo == ConvAlgo::Ws1x1 || s.algo == ConvAlgo::Ws3x3 || s.algo == ConvAlgo::Stem || s.algo == ConvAlgo::Direct) {
+                } else if (s.algo == ConvAlgo::Ws1x1 || s.algo == ConvAlgo::Ws3x3 || s.algo == ConvAlgo::Stem || s.algo == ConvAlgo::Direct || s.algo == ConvAlgo::Wino3x3) {
                     s.splitk = 1;
                 } else if (s.algo != ConvAlgo::Naive) {
                     // split-K when the output grid cannot fill the chip: aim for >= ~768 workgroups, keep >= 2 K-tiles
@@ -1230,7 +1239,7 @@ static std::string json_escape(const std::string& s) {
 
 std::string PlanToJson(const Plan& p) {
     static const char* kinds[] = {"conv", "pool", "gap", "eltwise", "copy"};
-    static const char* algos[] = {"igemm_vec", "igemm_scalar", "naive", "raster3x3", "ws1x1", "ws3x3", "stem", "direct", "igemm_f8", "dense_fused"};
+    static const char* algos[] = {"igemm_vec", "igemm_scalar", "naive", "raster3x3", "ws1x1", "ws3x3", "stem", "direct", "igemm_f8", "dense_fused", "wino3x3"};
     std::ostringstream o;
     o.precision(17);
     o << "{\"inputs\":[";

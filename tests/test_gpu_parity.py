@@ -1542,3 +1542,33 @@ def test_fused_dense_layer_kernel(tmp_path, batch, image, blocks, fuse_tile):
     e, e0 = rel_err(y, ref), rel_err(y0, ref)
     print(f"fused dense layers B={batch} image={image}: {len(nf)} fused steps (tiles {sorted({s['tile'] for s in nf})}), rel err {e:.2e} (unfused {e0:.2e})")
     assert e < RTOL and e0 < RTOL and rel_err(y, y0) < 2e-5
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("batch,image,blocks", [(3, 64, (2, 2)), (2, 112, (3,)), (5, 48, (2, 1))])
+def test_winograd_3x3_kernel(tmp_path, tile, batch, image, blocks):
+    """conv3x3_wino_kernel (Winograd F(2x2, 3x3): 16 multiplies per 2x2 output tile instead of 36) forced onto every eligible growth
+    conv of DenseNet-shaped graphs (32 output channels, even image sizes 16 / 28 / 12 / 8 / 6 with ragged tile blocks), all four
+    workgroup tile shapes, against the float64 oracle and against the planner's own choice of kernels."""
+    mb = models.densenet(batch, growth=32, blocks=blocks, stem=64, image=image, classes=12, seed=41)
+    path = models.write_repo(str(tmp_path), "wino", mb)
+    x = models.synthetic_input((batch, 3, image, image), stream="wino")
+    ref = O.run(O.load_model(mb), {"data_0": x}, dtype=np.float64)["fc6_1"]
+
+    def go():
+        plan = B.DescribeModel(path, batch)["plan"]
+        m = B.CreateModel(path, "wino")
+        try:
+            y = infer(m, "", "data_0", x, "fc6_1", [batch, 12, 1, 1])[0].copy()
+            y2 = infer(m, "", "data_0", x, "fc6_1", [batch, 12, 1, 1])[0]
+        finally:
+            m.Destroy()
+        np.testing.assert_array_equal(y, y2)
+        return plan, y
+    plan, y = _run_with_env(dict(IE_FORCE_ALGO="wino", IE_FORCE_TILE=str(tile)), go)
+    nw = [s for s in plan["steps"] if s.get("algo") == "wino3x3"]
+    assert len(nw) == sum(blocks) and all(s["out"]["c"] == 32 for s in nw)
+    _, y0 = _run_with_env(dict(IE_AUTOTUNE="0"), go)
+    e = rel_err(y, ref)
+    print(f"winograd tile {tile} B={batch} image={image}: {len(nw)} convs, rel err {e:.2e} (default kernels {rel_err(y0, ref):.2e})")
+    assert e < RTOL and rel_err(y, y0) < 2e-5
