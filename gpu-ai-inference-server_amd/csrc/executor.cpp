@@ -256,13 +256,20 @@ void DeviceModel::BuildInstance(PlanInstance& pi, const std::vector<std::vector<
                     w_->device_bytes += w_->weight_floats * sizeof(float);
                 }
                 // Winograd-transformed weights for the 3x3 / s1 / p1 convs with 32 output channels (kernels_wino.hip)
+                // (every such conv of the graph, also the ones this first plan instance runs inside a fused dense-layer step: the weights are
+                // shared by all plan instances, and another batch size fuses other layers)
                 int64_t utot = 0;
-                for (const Step& st : pi.plan.steps)
-                    if (st.parts.empty() && st.kind == StepKind::Conv && st.w_off >= 0 && st.kh == 3 && st.kw == 3 && st.sh == 1 && st.sw == 1 && st.pt == 1 && st.pl == 1 &&
-                        st.out.c == 32 && st.in.c % 16 == 0 && !st.in.nchw) {
+                auto add_wino = [&](const Step& st) {
+                    if (st.kind == StepKind::Conv && st.w_off >= 0 && st.kh == 3 && st.kw == 3 && st.sh == 1 && st.sw == 1 && st.pt == 1 && st.pl == 1 &&
+                        st.out.c == 32 && st.in.c % 32 == 0 && !st.in.nchw) {
                         w_->wino_regions.push_back({st.w_off, utot, 32, int(st.in.c)});
                         utot += int64_t(16) * 32 * st.in.c;
                     }
+                };
+                for (const Step& st : pi.plan.steps) {
+                    if (st.parts.empty()) add_wino(st);
+                    else for (const Step& q : st.parts) add_wino(q);
+                }
                 if (utot > 0) {
                     check(hipMalloc(reinterpret_cast<void**>(&w_->d_weights_wino), size_t(utot) * sizeof(float)), "hipMalloc(weights_wino)");
                     w_->device_bytes += size_t(utot) * sizeof(float);
@@ -813,7 +820,8 @@ void DeviceModel::Autotune(PlanInstance& pi, size_t nsteps, bool allow_search) {
             searched = true;
             float best = 1e30f;
             int best_tile = s.tile, best_split = s.splitk;
-            auto time_trial = [&](const Step& trial) {
+            static const bool tune_log = [] { const char* e = std::getenv("IE_TUNE_LOG"); return e && std::atoi(e) != 0; }();
+            auto time_trial_raw = [&](const Step& trial) {
                 LaunchStep(pi, trial, stream_);              // warm
                 float best_ms = 1e30f;
                 if (scrub) {
@@ -841,6 +849,13 @@ void DeviceModel::Autotune(PlanInstance& pi, size_t nsteps, bool allow_search) {
                     best_ms = std::min(best_ms, ms);
                 }
                 return best_ms;
+            };
+            auto time_trial = [&](const Step& trial) {
+                const float ms = time_trial_raw(trial);
+                if (tune_log)
+                    std::fprintf(stderr, "[ie-tune] M=%lld N=%lld K=%lld algo=%d tile=%d splitk=%d: %.4f ms\n", static_cast<long long>(M), static_cast<long long>(N),
+                                 static_cast<long long>(s.kh * s.kw * s.in.c), int(trial.algo), trial.tile, trial.splitk, ms);
+                return ms;
             };
             // LDS-window kernel for 3x3/s1/p1 convs without an activation prologue
             if (!s.in.f16 && !s.out.f16 && s.algo == ConvAlgo::IgemmVec && s.kh == 3 && s.kw == 3 && s.sh == 1 && s.sw == 1 && s.pt == 1 && s.pl == 1 && s.pb == 1 &&
@@ -875,7 +890,13 @@ void DeviceModel::Autotune(PlanInstance& pi, size_t nsteps, bool allow_search) {
                 probe_step.algo = ConvAlgo::Wino3x3;
                 ConvArgs probe = MakeConvArgs(pi, probe_step);
                 for (int t = 0; t < kNumConvWinoTiles; ++t) {
-                    if (!ConvWinoEligible(probe, t)) continue;
+                    if (!ConvWinoEligible(probe, t)) {
+                        if (tune_log)
+                            std::fprintf(stderr, "[ie-tune] M=%lld wino tile %d ineligible: wfrag=%p in(c=%d h=%d w=%d sw=%lld sh=%lld sn=%lld p=%p) out(c=%d sw=%lld p=%p) bias=%p pre=%p\n",
+                                         static_cast<long long>(M), t, (const void*)probe.wfrag, probe.in.c, probe.in.h, probe.in.w, (long long)probe.in.sw, (long long)probe.in.sh,
+                                         (long long)probe.in.sn, (void*)probe.in.p, probe.out.c, (long long)probe.out.sw, (void*)probe.out.p, (const void*)probe.bias, (const void*)probe.pre_scale);
+                        continue;
+                    }
                     Step trial = s;
                     trial.algo = ConvAlgo::Wino3x3;
                     trial.tile = t;

@@ -981,7 +981,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                            n.kh * n.kw <= 49;
                 };
                 const bool raster_ok = vec_ok && !s.out.f16 && is3x3 && !n.has_pre;
-                const bool wino_ok = raster_ok && N == 32 && s.in.c % 16 == 0 && s.in.h % 2 == 0 && s.in.w % 2 == 0 && n.res < 0 && s.out.pitch % 4 == 0 && s.out.c_off % 4 == 0;
+                const bool wino_ok = raster_ok && N == 32 && s.in.c % 32 == 0 && s.in.h % 2 == 0 && s.in.w % 2 == 0 && n.res < 0 && s.out.pitch % 4 == 0 && s.out.c_off % 4 == 0;
                 // ---- default choice without the autotuner (IE_AUTOTUNE=0, or before Prepare() has timed anything): the kernels
                 //      the exhaustive search picks for DenseNet / ResNet shapes ----
                 if (s.algo == ConvAlgo::IgemmF8) {
@@ -1030,7 +1030,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                         if (wino_ok) {
                             s.algo = ConvAlgo::Wino3x3;
                             s.tile = 0;
-                            if (const char* ft = std::getenv("IE_FORCE_TILE")) { int t = std::atoi(ft); if (t >= 0 && t < 8) s.tile = t; }
+                            if (const char* ft = std::getenv("IE_FORCE_TILE")) { int t = std::atoi(ft); if (t >= 0 && t < 4) s.tile = t; }
                         } else if (s.algo == ConvAlgo::Naive)
                             s.algo = (vec_ok || vec16_ok) ? ConvAlgo::IgemmVec : (K <= 2048 && !in16 ? ConvAlgo::IgemmScalar : ConvAlgo::Naive);
                     }
@@ -1038,7 +1038,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                         if (raster_ok) {
                             s.algo = ConvAlgo::Raster3x3;
                             s.tile = 0;
-                            if (const char* ft = std::getenv("IE_FORCE_TILE")) { int t = std::atoi(ft); if (t >= 0 && t < 8) s.tile = t; }
+                            if (const char* ft = std::getenv("IE_FORCE_TILE")) { int t = std::atoi(ft); if (t >= 0 && t < 4) s.tile = t; }
                         } else if (s.algo == ConvAlgo::Naive)
                             s.algo = (vec_ok || vec16_ok) ? ConvAlgo::IgemmVec : (K <= 2048 && !in16 ? ConvAlgo::IgemmScalar : ConvAlgo::Naive);
                     }
