@@ -123,7 +123,7 @@ hipError_t LaunchConvStem(const ConvArgs& a, hipStream_t stream);
 hipError_t InitKernelsStem();
 // Winograd F(2x2, 3x3) conv (kernels_wino.hip): fp32, 3x3 / stride 1 / pad 1, 32 output channels, even H and W; a.wfrag = the transformed
 // weights U (16 x Cout x Cin floats, fragment-major) built by LaunchWinogradWeights.  tile: 0..3 = output tiles per workgroup.
-constexpr int kNumConvWinoTiles = 4;        // output tiles per workgroup: 4x7, 2x14, 4x8, 2x16
+constexpr int kNumConvWinoTiles = 8;        // output tiles per workgroup: 4x7, 2x14, 4x8, 2x16; 0..3 four waves, 4..7 eight waves
 bool ConvWinoEligible(const ConvArgs& a, int tile);
 hipError_t LaunchConvWino3x3(const ConvArgs& a, int tile, hipStream_t stream);
 hipError_t LaunchWinogradWeights(const float* w, float* u, int Cout, int Cin, hipStream_t stream);

@@ -560,14 +560,19 @@ static bool as_eligible(const ConvArgs& a, int at) {
     const int64_t M = int64_t(a.out.n) * a.out.h * a.out.w;
     if (M > (int64_t(1) << 22) || M * a.in.sw * 4 >= (int64_t(1) << 31) || M * a.out.sw * 4 >= (int64_t(1) << 31) || int64_t(a.out.c) * a.in.c * 4 >= (int64_t(1) << 31))
         return false;
-    return size_t(16 * t.pb) * (a.in.c + 4) * 4 <= size_t(160) * 1024;
+    return size_t(16 * t.pb) * (a.in.c + 8) * 4 <= size_t(160) * 1024;
 }
 
 template <int AT>
 static hipError_t launch_as_t(const ConvArgs& a_in, hipStream_t stream) {
     constexpr AsTile t = kAsTiles[AT];
     ConvArgs a = a_in;
-    static const int pad = [] { const char* e = std::getenv("IE_AS_PAD"); const int v = e ? std::atoi(e) : 4; return (v >= 4 && v <= 68 && v % 4 == 0) ? v : 4; }();
+    // Row pad of the LDS activation tile.  ds_read_b128 is served in four 16-lane groups ({0-3,12-15,20-27}, ...): with a pad of 4 floats
+    // (row pitch = 4 mod 64 banks for K % 64 == 0) pixel row 11 of k-group 1 and row 12 of k-group 0 of one group share a 16-byte slot:
+    // every fragment read 2-way conflicted (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.45 in profiles/r01 and r02).  A pad of 8 floats
+    // (pitch = 8 or 40 mod 64 for K % 32 == 0) is conflict-free: the counter reads 0 and the LDS-active cycles halve -- at unchanged
+    // kernel time (0.610 ms -> 0.610 ms per forward): the kernel was never LDS-bound.
+    static const int pad = [] { const char* e = std::getenv("IE_AS_PAD"); const int v = e ? std::atoi(e) : 8; return (v >= 4 && v <= 68 && v % 4 == 0) ? v : 8; }();
     a.debug = pad << 8;
     const int64_t M = int64_t(a.out.n) * a.out.h * a.out.w;
     const dim3 grid(unsigned((M + 16 * t.pb - 1) / (16 * t.pb)), unsigned(a.out.c / (16 * t.tnw * t.waves)));

@@ -80,8 +80,13 @@ struct WinoGeom {
 //   * no transformed-tile buffer in LDS, ONE barrier per 16-channel slice (the window is double-buffered and register-prefetched two
 //     slices ahead), the LDS reads of the next stage are issued before the MFMAs of the current one;
 //   * U fragments come straight from the fragment-major mirror in L2, two stages ahead.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_wino_kernel(const ConvArgs a, const WinoGeom g) {
-    constexpr int NT = 256, CS = 16, LP = CS + 4, MP = 32 + 4, PITW = 4;
+// WAVES = 8 (tiles 4..7): two positions per wave instead of four -- half the MFMA chain per wave, four waves per SIMD instead of two
+// (124 VGPRs), at 10 v_pk per 8 MFMAs instead of 16 per 16.  Measured (wino_probe, 56x56x128 -> 32): one workgroup per CU 15.7 us
+// against 19.3, 3.5 per CU (batch 32) 50.0 us against 56.2; sixteen waves (one position each) gave nothing more (15.6 / 57.5).
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, WAVES == 8 ? 4 : 2))) void conv3x3_wino_kernel(const ConvArgs a, const WinoGeom g) {
+    constexpr int NT = 64 * WAVES, CS = 16, LP = CS + 4, MP = 32 + 4, PITW = 1024 / NT;
+    constexpr int NJ = 16 / WAVES;                      // positions (columns j of row i) per wave
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) float smem_wino[];
     const int WR = 2 * g.TR + 2, WC = 2 * g.TC + 2, npx = WR * WC;
@@ -134,51 +139,62 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (it < items) *reinterpret_cast<f32x4*>(w + (it >> 2) * LP + (it & 3) * 4) = pv[i];
         }
     };
-    // Row i = wave of the transformed tile: m_c = d[ra][c] + sg * d[rb][c] with (ra, rb, sg) = (0,2,-), (1,2,+), (2,1,-), (1,3,-).
-    const int ra = wave == 0 ? 0 : wave == 2 ? 2 : 1, rb = wave == 2 ? 1 : wave == 3 ? 3 : 2;
-    const float sg = wave == 1 ? 1.f : -1.f;
+    // Row i of the transformed tile: m_c = d[ra][c] + sg * d[rb][c] with (ra, rb, sg) = (0,2,-), (1,2,+), (2,1,-), (1,3,-).
+    const int wi = wave / (WAVES / 4), jh = wave % (WAVES / 4);       // this wave's row and (8 waves) its pair of columns
+    const int ra = wi == 0 ? 0 : wi == 2 ? 2 : 1, rb = wi == 2 ? 1 : wi == 3 ? 3 : 2;
+    const float sg = wi == 1 ? 1.f : -1.f;
+    constexpr int NC = NJ == 4 ? 4 : 3;                 // window columns a wave needs: all four, or jh .. jh+2
     // Lanes beyond the block's tiles read in-allocation garbage; their accumulator rows are never read by the epilogue.
     const int ltr = r / g.TC, ltc = r - ltr * g.TC;
-    const int dA = ((2 * ltr + ra) * WC + 2 * ltc) * LP + hh * 4, dB = ((2 * ltr + rb) * WC + 2 * ltc) * LP + hh * 4;
+    const int col0 = NJ == 4 ? 0 : jh;
+    const int dA = ((2 * ltr + ra) * WC + 2 * ltc + col0) * LP + hh * 4, dB = ((2 * ltr + rb) * WC + 2 * ltc + col0) * LP + hh * 4;
     const int c8n = Cin >> 3;
-    u32x4 ub0[4], ub1[4];
-    auto issue_u = [&](u32x4 (&ub)[4], int h) {
+    u32x4 ub0[NJ], ub1[NJ];
+    auto issue_u = [&](u32x4 (&ub)[NJ], int h) {
 #pragma unroll
-        for (int xl = 0; xl < 4; ++xl)
-            ub[xl] = __builtin_amdgcn_raw_buffer_load_b128(rs_u, h < nstages ? unsigned(((4 * wave + xl) * c8n + h) * 64 + lane) * 16u : OOB, 0, 0);
+        for (int xl = 0; xl < NJ; ++xl)
+            ub[xl] = __builtin_amdgcn_raw_buffer_load_b128(rs_u, h < nstages ? unsigned(((NJ * wave + xl) * c8n + h) * 64 + lane) * 16u : OOB, 0, 0);
     };
-    f32x4 dra[4], drb[4];                               // window rows ra / rb, four columns, this lane's four channels
+    f32x4 dra[NC], drb[NC];                             // window rows ra / rb, the wave's columns, this lane's four channels
     auto read_d = [&](int buf, int half) {
         const float* const w = sWin + buf * win_floats + half * 8;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < NC; ++c) {
             dra[c] = *reinterpret_cast<const f32x4*>(w + dA + c * LP);
             drb[c] = *reinterpret_cast<const f32x4*>(w + dB + c * LP);
         }
     };
-    f32x4 af[4];                                        // A fragments of the next stage: V[wave][j], four channels
+    f32x4 af[NJ];                                       // A fragments of the next stage: V[wi][j], four channels
     auto make_af = [&]() {
-        f32x4 m[4];
+        f32x4 m[NC];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) m[c] = dra[c] + sg * drb[c];
-        af[0] = m[0] - m[2];
-        af[1] = m[1] + m[2];
-        af[2] = m[2] - m[1];
-        af[3] = m[1] - m[3];
+        for (int c = 0; c < NC; ++c) m[c] = dra[c] + sg * drb[c];
+        if constexpr (NJ == 4) {
+            af[0] = m[0] - m[2];
+            af[1] = m[1] + m[2];
+            af[2] = m[2] - m[1];
+            af[3] = m[1] - m[3];
+        } else if (jh == 0) {                           // columns 0..2: V[i][0], V[i][1]
+            af[0] = m[0] - m[2];
+            af[1] = m[1] + m[2];
+        } else {                                        // columns 1..3: V[i][2], V[i][3]
+            af[0] = m[1] - m[0];
+            af[1] = m[0] - m[2];
+        }
     };
-    f32x16 acc[4];
+    f32x16 acc[NJ];
 #pragma unroll
-    for (int xl = 0; xl < 4; ++xl)
+    for (int xl = 0; xl < NJ; ++xl)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[xl][e] = 0.f;
-    auto mfmas = [&](const u32x4 (&ub)[4]) {
-        f32x4 ac[4];
+    auto mfmas = [&](const u32x4 (&ub)[NJ]) {
+        f32x4 ac[NJ];
 #pragma unroll
-        for (int xl = 0; xl < 4; ++xl) ac[xl] = af[xl];
+        for (int xl = 0; xl < NJ; ++xl) ac[xl] = af[xl];
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int xl = 0; xl < 4; ++xl)
+            for (int xl = 0; xl < NJ; ++xl)
                 acc[xl] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[xl][e], __builtin_bit_cast(f32x4, ub[xl])[e], acc[xl], 0, 0, 0);
     };
 
@@ -221,11 +237,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         if (half) __syncthreads();
-        if ((wave >> 1) == half) {
+        if ((wi >> 1) == half) {
 #pragma unroll
-            for (int xl = 0; xl < 4; ++xl)
+            for (int xl = 0; xl < NJ; ++xl)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) sM[((4 * (wave & 1) + xl) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh) * MP + r] = acc[xl][e];
+                for (int e = 0; e < 16; ++e) sM[((4 * (wi & 1) + NJ * jh + xl) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh) * MP + r] = acc[xl][e];
         }
         __syncthreads();
 #pragma unroll
@@ -270,7 +286,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 struct WinoTile { int tr, tc; };
-constexpr WinoTile kWinoTiles[kNumConvWinoTiles] = {{4, 7}, {2, 14}, {4, 8}, {2, 16}};
+constexpr WinoTile kWinoTiles[kNumConvWinoTiles] = {{4, 7}, {2, 14}, {4, 8}, {2, 16}, {4, 7}, {2, 14}, {4, 8}, {2, 16}};      // 4..7: eight waves
 
 static size_t wino_lds_bytes(int tr, int tc) {
     const size_t npx = size_t(2 * tr + 2) * (2 * tc + 2);
@@ -307,12 +323,15 @@ hipError_t LaunchConvWino3x3(const ConvArgs& a_in, int tile, hipStream_t stream)
     g.brx = (g.TW + g.TC - 1) / g.TC;
     const int64_t blocks = int64_t(a.in.n) * g.bry * g.brx;
     if (blocks >= (int64_t(1) << 31)) return hipErrorInvalidValue;
-    conv3x3_wino_kernel<<<dim3(unsigned(blocks)), dim3(256), wino_lds_bytes(t.tr, t.tc), stream>>>(a, g);
+    if (tile >= 4) conv3x3_wino_kernel<8><<<dim3(unsigned(blocks)), dim3(512), wino_lds_bytes(t.tr, t.tc), stream>>>(a, g);
+    else conv3x3_wino_kernel<4><<<dim3(unsigned(blocks)), dim3(256), wino_lds_bytes(t.tr, t.tc), stream>>>(a, g);
     return hipGetLastError();
 }
 
 hipError_t InitKernelsWino() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
 }
 
 }  // namespace ie

@@ -1544,7 +1544,7 @@ def test_fused_dense_layer_kernel(tmp_path, batch, image, blocks, fuse_tile):
     assert e < RTOL and e0 < RTOL and rel_err(y, y0) < 2e-5
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("batch,image,blocks", [(3, 64, (2, 2)), (2, 112, (3,)), (5, 48, (2, 1))])
 def test_winograd_3x3_kernel(tmp_path, tile, batch, image, blocks):
     """conv3x3_wino_kernel (Winograd F(2x2, 3x3): 16 multiplies per 2x2 output tile instead of 36) forced onto every eligible growth
