@@ -29,6 +29,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
+// Pad (floats) of the LDS pixel rows.  The fragment reads are ds_read_b128 at row * pitch + k-group * 4: with a pad of 4 two lanes of
+// every 16-lane service group share a 16-byte slot (2-way conflict on every read, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.42 in
+// profiles/r02); pitch = 8 mod 32 banks is conflict-free for channel counts that are multiples of 32 (kernels_direct.hip, launch_as_t).
+constexpr int kRowPad = 8;
+
 // PB: 16-pixel blocks per workgroup.  8 waves.  1x1: Cout == 128 (16 per wave).  3x3: stride 1, pad 1, Cout == 32, 9 * Cin3 / 16 <= 72 chunks.
 // OCC2: a variant meant to run TWO workgroups per CU (16-pixel tiles, <= 128 VGPRs, <= 80 KB of LDS): the old-channel loads are issued only
 // after the 3x3's MFMAs (their registers would otherwise overlap the 3x3's weight fragments); the latency this exposes is what the
@@ -40,7 +45,7 @@ void conv_dense_fused_kernel(const ConvArgs a, const FusedArgs f, const int part
     constexpr int MAXS = PB == 1 ? 8 : 16;             // staging slots per thread for the old channels: PX * (K - 32) / 4 <= MAXS * NT
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_fused[];
-    const int K = a.in.c, Kold = K - 32, P = K + 4, CH = K >> 4, Cin3 = f.in3.c, P3 = Cin3 + 4;
+    const int K = a.in.c, Kold = K - 32, P = K + kRowPad, CH = K >> 4, Cin3 = f.in3.c, P3 = Cin3 + kRowPad;
     float* const sA = reinterpret_cast<float*>(smem_fused);                        // [PX][P]: the 1x1's activation rows
     float* const sWin = sA;                                                        // [npx][P3]: bottleneck window of the 3x3; sA's rows are only
                                                                                    // written once every wave is done with the window
@@ -313,7 +318,7 @@ __global__ __launch_bounds__(512) void conv_dense_fused_ws_kernel(const ConvArgs
     constexpr int MAXS = PB == 1 ? 8 : 16, MAXW = 8;
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_fused[];
-    const int K = a.in.c, Kold = K - 32, P = K + 4, CH = K >> 4, Cin3 = f.in3.c, P3 = Cin3 + 4;
+    const int K = a.in.c, Kold = K - 32, P = K + kRowPad, CH = K >> 4, Cin3 = f.in3.c, P3 = Cin3 + kRowPad;
     float* const sA = reinterpret_cast<float*>(smem_fused);                        // [PX][P]
     float* const sWin = sA + win_off;                                              // [npx][P3]
     float* const sPart = sA + part_off;                                            // [CW][PX][PP]
@@ -572,7 +577,7 @@ __global__ __launch_bounds__(512) void conv_dense_fused_ws_kernel(const ConvArgs
 // LDS of the wave-specialised variant: rows, window, partial tiles (4 waves) and two counters, nothing shared
 static size_t fused_ws_lds_bytes(const ConvArgs& a, const FusedArgs& f, int pb, int* win_off = nullptr, int* part_off = nullptr) {
     const size_t px = size_t(16) * pb;
-    const size_t rows = px * (a.in.c + 4) * 4, win = (px + 2 * a.in.w + 2) * (f.in3.c + 4) * 4, part = size_t(4) * px * 36 * 4;
+    const size_t rows = px * (a.in.c + kRowPad) * 4, win = (px + 2 * a.in.w + 2) * (f.in3.c + kRowPad) * 4, part = size_t(4) * px * 36 * 4;
     if (win_off) *win_off = int(rows / 4);
     if (part_off) *part_off = int((rows + win) / 4);
     return rows + win + part + 16;
@@ -582,7 +587,7 @@ static size_t fused_ws_lds_bytes(const ConvArgs& a, const FusedArgs& f, int pb, 
 // tiles of the 3x3 sit behind them.  Returns the partial tiles' offset in floats through part_off.
 static size_t fused_lds_bytes(const ConvArgs& a, const FusedArgs& f, int pb, int* part_off = nullptr) {
     const size_t px = size_t(16) * pb;
-    const size_t rows = px * (a.in.c + 4) * 4, win = (px + 2 * a.in.w + 2) * (f.in3.c + 4) * 4, part = size_t(4) * px * 36 * 4;
+    const size_t rows = px * (a.in.c + kRowPad) * 4, win = (px + 2 * a.in.w + 2) * (f.in3.c + kRowPad) * 4, part = size_t(4) * px * 36 * 4;
     const size_t first = (rows > win ? rows : win);
     if (part_off) *part_off = int(first / 4);
     return first + part;
