@@ -1001,6 +1001,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                     } else {
                         if (is1x1 && direct_ok(10)) { s.algo = ConvAlgo::Direct; s.tile = 10; }      // activations-stationary 1x1: 128-channel multiples whose 32 pixel rows fit in LDS
                         else if (is1x1 && M >= 20000) { for (int t : {0, 2, 4}) if (pick < 0 && ws32_ok(t)) pick = t; if (pick >= 0) { s.algo = ConvAlgo::Ws1x1; s.tile = pick; } }
+                        else if (wino_ok && M >= 20000) { s.algo = ConvAlgo::Wino3x3; s.tile = 5; }     // Winograd F(2x2,3x3), 2x14 tiles, eight waves (falls back to the tiled kernel without the U mirror)
                         else if (raster_ok && M >= 20000 && N <= 64) { s.algo = ConvAlgo::Raster3x3; s.tile = N <= 32 ? 0 : 4; }
                         else if (is3x3 && M <= 8192) { if (direct_ok(4)) { s.algo = ConvAlgo::Direct; s.tile = 4; } }
                     }

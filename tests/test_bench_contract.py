@@ -10,14 +10,26 @@ REQUIRED = {"metric": str, "value": (int, float), "unit": str, "n_gpus": int, "s
             "higher_is_better": bool, "scaling": str, "dtype": str, "data": str, "config": dict, "roofline": dict}
 
 
-@pytest.mark.parametrize("name,dtype", [("bench.json", "f32"), ("bench_f16_b128.json", "f16")])
-def test_committed_bench_lines_follow_the_contract(name, dtype):
+def _latest_round():
     rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if os.path.isdir(os.path.join(ROOT, "profiles", d)))
-    path = os.path.join(ROOT, "profiles", rounds[-1], name)
-    with open(path) as f:
+    return os.path.join(ROOT, "profiles", rounds[-1])
+
+
+def _headline():
+    with open(os.path.join(_latest_round(), "bench.json")) as f:
         lines = [ln for ln in f.read().splitlines() if ln.strip()]
     assert len(lines) == 1, "bench.py prints ONE JSON line"
-    d = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16", "f8"])
+def test_committed_bench_lines_follow_the_contract(dtype):
+    """The headline line, and the secondary configurations it carries since round 2 (same keys, run-level constants inherited)."""
+    d = _headline()
+    if dtype != "f32":
+        sec = [x for x in d.get("secondary", []) if x.get("dtype") == dtype]
+        assert len(sec) == 1, "one secondary entry per precision"
+        d = dict({k: d[k] for k in ("n_gpus", "higher_is_better", "scaling", "vs_baseline", "data", "unit")}, **sec[0])
     for k, t in REQUIRED.items():
         assert k in d and isinstance(d[k], t), k
     assert "vs_baseline" in d and d["vs_baseline"] is None          # BASELINE.md publishes no number for this metric

@@ -66,11 +66,13 @@ def test_densenet121_plan(densenet_repo):
     b1 = [s for s in p["steps"] if s["kind"] == "conv" and s["k"] == [1, 1] and s["in"]["pitch"] == 256]
     assert all(s["pre"] and s["pre_relu"] and s["relu"] and s["bias"] for s in b1[:6])
     assert p["steps"][0]["algo"] == "stem" and p["steps"][0]["in"]["nchw"]              # stem kernel reads the ABI's NCHW directly
-    # default kernel choices before any autotuning: the activations-stationary 1x1 (kernels_direct.hip family) and the LDS-window 3x3
-    # for the big layers, the direct split-K / window tiles for the small grids, the tiled implicit GEMM for the rest
+    # default kernel choices before any autotuning: the activations-stationary 1x1 (kernels_direct.hip family) and the Winograd 3x3
+    # (eight waves, 2x14 output tiles) for the big layers of blocks 1-2, the direct split-K / window tiles for the small grids, the
+    # tiled implicit GEMM for the rest
     algos = [s["algo"] for s in p["steps"][2:] if s["kind"] == "conv"]
-    assert set(algos) <= {"igemm_vec", "ws1x1", "raster3x3", "direct"} and algos[0] == "direct" and algos[1] == "raster3x3"
-    assert algos.count("raster3x3") == 18 and algos.count("direct") >= 90
+    assert set(algos) <= {"igemm_vec", "ws1x1", "wino3x3", "direct"} and algos[0] == "direct" and algos[1] == "wino3x3"
+    assert algos.count("wino3x3") == 18 and algos.count("direct") >= 90
+    assert {s["tile"] for s in p["steps"] if s.get("algo") == "wino3x3"} == {5}
     tiles = {s["tile"] for s in p["steps"][2:] if s["kind"] == "conv" and s["algo"] == "direct"}
     assert {10, 13, 6} <= tiles, tiles
     assert p["outputs"][0]["dims"] == [32, 1000, 1, 1]
