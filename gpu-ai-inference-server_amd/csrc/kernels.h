@@ -128,6 +128,13 @@ bool ConvWinoEligible(const ConvArgs& a, int tile);
 hipError_t LaunchConvWino3x3(const ConvArgs& a, int tile, hipStream_t stream);
 hipError_t LaunchWinogradWeights(const float* w, float* u, int Cout, int Cin, hipStream_t stream);
 hipError_t InitKernelsWino();
+// fp32 1x1 conv on the bf16 matrix pipe with exactly split operands (kernels_x6.hip; opt-in, IE_FP32_SPLIT=1): `w16` points at the three
+// bf16 planes LaunchSplitWeightsX6 built from the conv's fp32 weights.  tile 0: 128 pixels per workgroup, 1: 64.
+constexpr int kNumConvX6Tiles = 2;
+bool ConvX6Eligible(const ConvArgs& a, int tile);
+hipError_t LaunchConvX6(const ConvArgs& a, int tile, hipStream_t stream);
+hipError_t LaunchSplitWeightsX6(const float* w, void* dst, int Cout, int K, hipStream_t stream);
+hipError_t InitKernelsX6();
 // Fused dense-layer step (fp32): 3x3 growth conv of layer L + 1x1 bottleneck conv of layer L+1 per 16*pb-pixel tile, one launch.
 // tile: 1 / 2 = 16-pixel blocks per workgroup; 3 = 16-pixel tiles, two workgroups per CU (<= 128 VGPRs, <= 80 KB LDS);
 // 4 / 5 = wave-specialised variant (3x3 and 1x1 run concurrently on different waves), 16 / 32 pixels
