@@ -372,6 +372,7 @@ bool ModelObj::Load() {
                 u8_bias = conf.uint8_bias;
                 ie::DeviceModelOptions opt;
                 opt.precision = prec;
+                opt.fp32_split = conf.fp32_split;
                 opt.tune_cache_path = path + "/.ie_tune." + (prec == ie::Precision::F16 ? "fp16" : (prec == ie::Precision::F8 ? "fp8" : "fp32")) + ".txt";
                 auto primary = std::make_unique<ie::DeviceModel>(parsed, device_id, opt);
                 primary->SetU8Transform(u8_scale, u8_bias);
@@ -1062,12 +1063,13 @@ std::string describe_runtime(ModelObj& M, bool json, bool checksums = false) {
     std::ostringstream o;
     o.precision(6);
     if (!json) {
-        o << "mi355x-engine precision=" << pname << " lanes=" << M.lanes.size() << " shards=" << (up ? M.num_shards : 0) << " forwards=" << fw
+        o << "mi355x-engine precision=" << pname << (up && !M.lanes.empty() && M.lanes[0]->fp32_split() ? "+bf16x6" : "") << " lanes=" << M.lanes.size() << " shards=" << (up ? M.num_shards : 0) << " forwards=" << fw
           << " images=" << im << " device_ms_avg=" << (fw ? ms / double(fw) : 0.0) << " achieved_tflops=" << tflops << " frac_mfma_peak=" << tflops / mfma_peak
           << " algorithmic_gbs=" << gbs << " frac_hbm_peak=" << gbs / 8000.0;
         return o.str();
     }
-    o << "{\"loaded\":" << (up ? "true" : "false") << ",\"precision\":\"" << pname << "\",\"lanes\":" << M.lanes.size() << ",\"shards\":" << (up ? M.num_shards : 0)
+    o << "{\"loaded\":" << (up ? "true" : "false") << ",\"precision\":\"" << pname << "\",\"fp32_split\":" << (up && !M.lanes.empty() && M.lanes[0]->fp32_split() ? "true" : "false")
+      << ",\"lanes\":" << M.lanes.size() << ",\"shards\":" << (up ? M.num_shards : 0)
       << ",\"lane_devices\":[";
     for (size_t i = 0; i < M.lanes.size(); ++i) o << (i ? "," : "") << M.lanes[i]->device();
     o << "],\"lane_shares_weights_with\":[";
@@ -1236,7 +1238,7 @@ char* EngineDescribeModel(const char* path, int batch, ErrorMessage* error) {
               << "\",\"platform\":\"" << esc(c.platform) << "\",\"precision\":\"" << esc(c.precision) << "\",\"gpus\":" << c.gpus
               << ",\"uint8_scale\":" << c.uint8_scale << ",\"uint8_bias\":" << c.uint8_bias << ",\"dynamic_batching\":" << (c.dynamic_batching ? "true" : "false")
               << ",\"max_batch_size\":" << c.max_batch_size << ",\"batch_window_us\":" << c.batch_window_us << ",\"instance_count\":" << c.instance_count
-              << ",\"tune_batches\":[";
+              << ",\"fp32_split\":" << (c.fp32_split ? "true" : "false") << ",\"tune_batches\":[";
             for (size_t k = 0; k < c.tune_batches.size(); ++k) o << (k ? "," : "") << c.tune_batches[k];
             o << "],\"inputs\":";
             io(c.inputs);

@@ -200,6 +200,7 @@ EngineConfig ParseEngineConfig(const std::string& json_text) {
     c.batch_window_us = int_of(doc.find("batch_window_us"), -1);
     c.instance_count = int_of(doc.find("instance_count"), 0);
     c.tune_batches = int_list(doc.find("tune_batches"));
+    if (const JsonValue* v = doc.find("fp32_split"); v && v->type == JsonValue::Bool) c.fp32_split = v->b;
     return c;
 }
 

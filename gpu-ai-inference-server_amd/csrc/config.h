@@ -10,6 +10,7 @@
 //   "dynamic_batching": bool, "max_batch_size": n, "batch_window_us": n     request coalescing (model.h:63,70-71 carries the first two)
 //   "instance_count": n                          concurrent execution lanes per model (model.h:63)
 //   "tune_batches": [b, ...]                     batch sizes to plan + autotune at load (besides inputs[0].shape[0])
+//   "fp32_split": true                           fp32 mode: allow the bf16x6 kernels (fp32 products from exactly split bf16 operands)
 #pragma once
 #include <cstdint>
 #include <string>
@@ -49,6 +50,7 @@ struct EngineConfig {
     int batch_window_us = -1;          // -1 = unset
     int instance_count = 0;            // 0 = unset
     std::vector<int64_t> tune_batches;
+    bool fp32_split = false;           // fp32 mode: let the search use the bf16x6 kernels (kernels_x6.hip)
 };
 
 EngineConfig ParseEngineConfig(const std::string& json_text);

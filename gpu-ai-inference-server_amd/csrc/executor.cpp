@@ -84,6 +84,7 @@ DeviceWeights::~DeviceWeights() {
     if (d_weights8) (void)hipFree(d_weights8);
     if (d_f8_aux) (void)hipFree(d_f8_aux);
     if (d_weights_wino) (void)hipFree(d_weights_wino);
+    if (d_weights_x6) (void)hipFree(d_weights_x6);
 }
 
 namespace {
@@ -91,7 +92,7 @@ namespace {
 std::string tune_file_header() {
     std::ostringstream o;
     o << kTuneFileTag << ' ' << kNumIgemmTiles << ' ' << kNumConvRasterTiles << ' ' << kNumConvWs32Tiles << ' ' << kNumConvWs3Tiles << ' '
-      << kNumConvDirectTiles << ' ' << kNumConvWinoTiles;
+      << kNumConvDirectTiles << ' ' << kNumConvWinoTiles << ' ' << kNumConvX6Tiles;
     return o.str();
 }
 
@@ -114,7 +115,7 @@ void load_tune_file(const std::string& path, std::map<std::vector<int64_t>, std:
         }
         int t = -1, sp = 0;
         if (ok && (is >> t >> sp) && ((t >= 0 && t < kNumIgemmTiles) || (t >= 100 && t < 100 + kNumConvRasterTiles) || (t >= 200 && t < 200 + kNumConvWs32Tiles) ||
-                                       (t >= 300 && t < 300 + kNumConvWs3Tiles) || (t >= 400 && t < 400 + kNumConvDirectTiles) || (t >= 500 && t < 500 + kNumConvWinoTiles)) &&
+                                       (t >= 300 && t < 300 + kNumConvWs3Tiles) || (t >= 400 && t < 400 + kNumConvDirectTiles) || (t >= 500 && t < 500 + kNumConvWinoTiles) || (t >= 600 && t < 600 + kNumConvX6Tiles)) &&
             sp >= 1 && sp <= 64 && key.size() >= 17)
             cache[key] = {t, sp};
     }
@@ -139,8 +140,11 @@ DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id, 
         if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsF8();
         if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsFused();
         if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsWino();
+        if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsX6();
     });
     check(g_kernels_err, "InitKernels");
+    fp32_split_ = opt.fp32_split && opt.precision == Precision::F32;
+    if (const char* e = std::getenv("IE_FP32_SPLIT")) fp32_split_ = std::atoi(e) != 0 && opt.precision == Precision::F32;
     if (opt.share) {
         if (opt.share->device != device_) throw std::runtime_error("internal error: shared weights live on another device");
         w_ = opt.share;
@@ -152,6 +156,7 @@ DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id, 
         // Persistent kernel-choice cache: IE_TUNE_CACHE=<file> (""/"0" = none), else the path the bridge derived from the model directory.
         std::string path = opt.tune_cache_path;
         if (const char* tc = std::getenv("IE_TUNE_CACHE")) path = (tc[0] == 0 || (tc[0] == '0' && tc[1] == 0)) ? std::string() : std::string(tc);
+        if (fp32_split_ && !path.empty()) path += ".x6";       // choices made with the bf16x6 kernels in the search are their own file
         w_->tune_cache_path = path;
         if (!path.empty()) load_tune_file(path, w_->tune_cache);
     }
@@ -274,6 +279,27 @@ void DeviceModel::BuildInstance(PlanInstance& pi, const std::vector<std::vector<
                     check(hipMalloc(reinterpret_cast<void**>(&w_->d_weights_wino), size_t(utot) * sizeof(float)), "hipMalloc(weights_wino)");
                     w_->device_bytes += size_t(utot) * sizeof(float);
                 }
+                // bf16x6 mirrors (opt-in): the 1x1 convs the split kernel can run, whatever step they are part of in this plan instance
+                const bool split = fp32_split_;
+                w_->fp32_split = split;
+                if (split) {
+                    int64_t xtot = 0;
+                    auto add_x6 = [&](const Step& st) {
+                        if (st.kind == StepKind::Conv && st.w_off >= 0 && st.kh == 1 && st.kw == 1 && st.sh == 1 && st.sw == 1 && st.out.c % 128 == 0 && st.in.c % 32 == 0 &&
+                            !st.in.nchw) {
+                            w_->x6_regions.push_back({st.w_off, xtot, int(st.out.c), int(st.in.c)});
+                            xtot += int64_t(3) * st.out.c * st.in.c * 2;
+                        }
+                    };
+                    for (const Step& st : pi.plan.steps) {
+                        if (st.parts.empty()) add_x6(st);
+                        else for (const Step& q : st.parts) add_x6(q);
+                    }
+                    if (xtot > 0) {
+                        check(hipMalloc(&w_->d_weights_x6, size_t(xtot)), "hipMalloc(weights_x6)");
+                        w_->device_bytes += size_t(xtot);
+                    }
+                }
             }
             if (w_->uploaded) WeightsArrived();
         } else if (pi.plan.weights.size() != w_->weight_floats) {
@@ -376,6 +402,9 @@ PlanInstance& DeviceModel::Prepare(const std::vector<std::vector<int64_t>>& shap
 // Rebuilds what is derived from the fp32 weight blob: the half mirror (fp16 mode) or the fragment-major conv weights (fp32 mode).
 void DeviceModel::WeightsArrived() {
     w_->uploaded = true;
+    if (w_->d_weights_x6)
+        for (const auto& xr : w_->x6_regions)
+            check(LaunchSplitWeightsX6(w_->d_weights + xr.w_off, static_cast<char*>(w_->d_weights_x6) + xr.byte_off, xr.cout, xr.k, stream_), "split_weights_x6");
     if (w_->d_weights_wino) {
         check(hipSetDevice(device_), "hipSetDevice");
         for (const auto& wr : w_->wino_regions)
@@ -723,7 +752,7 @@ void DeviceModel::Autotune(PlanInstance& pi, size_t nsteps, bool allow_search) {
             }
             const Step planned = s;                    // the planner's default, kept when nothing better is known
             // the planner's default may already name a specialised kernel: the search starts from the tiled implicit GEMM either way
-            if (s.algo == ConvAlgo::Ws1x1 || s.algo == ConvAlgo::Ws3x3 || s.algo == ConvAlgo::Direct || s.algo == ConvAlgo::Raster3x3 || s.algo == ConvAlgo::Wino3x3) {
+            if (s.algo == ConvAlgo::Ws1x1 || s.algo == ConvAlgo::Ws3x3 || s.algo == ConvAlgo::Direct || s.algo == ConvAlgo::Raster3x3 || s.algo == ConvAlgo::Wino3x3 || s.algo == ConvAlgo::X6) {
                 s.algo = ConvAlgo::IgemmVec;
                 s.tile = s.base_tile;
                 s.splitk = 1;
@@ -774,7 +803,8 @@ void DeviceModel::Autotune(PlanInstance& pi, size_t nsteps, bool allow_search) {
             if (s.in.f16 || s.out.f16) { key.push_back(s.in.f16); key.push_back(s.out.f16); }   // fp32 signatures keep 17 entries
             if (s.has_in2) key.push_back(1);              // a fused residual changes which kernels apply (18 / 20 entries)
             auto apply = [&](int enc_tile, int sp) {     // tile >= 100 encodes the raster kernel, >= 200 the weights-stationary 1x1
-                if (enc_tile >= 500) { s.algo = ConvAlgo::Wino3x3; s.tile = enc_tile - 500; }
+                if (enc_tile >= 600) { s.algo = ConvAlgo::X6; s.tile = enc_tile - 600; }
+                else if (enc_tile >= 500) { s.algo = ConvAlgo::Wino3x3; s.tile = enc_tile - 500; }
                 else if (enc_tile >= 400) { s.algo = ConvAlgo::Direct; s.tile = enc_tile - 400; }
                 else if (enc_tile >= 300) { s.algo = ConvAlgo::Ws3x3; s.tile = enc_tile - 300; }
                 else if (enc_tile >= 200) { s.algo = ConvAlgo::Ws1x1; s.tile = enc_tile - 200; }
@@ -905,6 +935,21 @@ void DeviceModel::Autotune(PlanInstance& pi, size_t nsteps, bool allow_search) {
                     if (ms < best) { best = ms; best_tile = 500 + t; best_split = 1; }
                 }
             }
+            // bf16x6 (opt-in): the 1x1 convs on the bf16 matrix pipe with exactly split operands
+            if (w_->d_weights_x6 && !s.in.f16 && !s.out.f16 && s.algo == ConvAlgo::IgemmVec && s.kh == 1 && s.kw == 1 && !s.has_in2) {
+                Step probe_step = s;
+                probe_step.algo = ConvAlgo::X6;
+                ConvArgs probe = MakeConvArgs(pi, probe_step);
+                for (int t = 0; t < kNumConvX6Tiles; ++t) {
+                    if (!ConvX6Eligible(probe, t)) continue;
+                    Step trial = s;
+                    trial.algo = ConvAlgo::X6;
+                    trial.tile = t;
+                    trial.splitk = 1;
+                    float ms = time_trial(trial);
+                    if (ms < best) { best = ms; best_tile = 600 + t; best_split = 1; }
+                }
+            }
             // the kernels_direct.hip family (every variant checks its own pixel-count / shape limits): K split over the waves with
             // operands straight from global memory, LDS-window tiles, activations-stationary 1x1, window + streamed weights
             if (s.algo == ConvAlgo::IgemmVec) {
@@ -1024,6 +1069,11 @@ ConvArgs DeviceModel::MakeConvArgs(const PlanInstance& pi, const Step& s) const 
     a.workspace_floats = pi.workspace_floats;
     a.counters = pi.counters;
     a.num_counters = pi.counters ? kNumCounters : 0;
+    if (s.algo == ConvAlgo::X6) {                    // the split kernel reads its three bf16 planes through `w16`
+        a.w16 = nullptr;
+        for (const auto& xr : w_->x6_regions)
+            if (xr.w_off == s.w_off && w_->d_weights_x6) a.w16 = static_cast<const char*>(w_->d_weights_x6) + xr.byte_off;
+    }
     if (s.algo == ConvAlgo::Wino3x3) {               // the Winograd kernel reads the transformed weights through `wfrag`
         a.wfrag = nullptr;
         for (const auto& wr : w_->wino_regions)
@@ -1080,6 +1130,7 @@ void DeviceModel::LaunchStep(const PlanInstance& pi, const Step& s_in, hipStream
                     case ConvAlgo::Direct: ok = ConvDirectEligible(plain, s_in.tile); break;
                     case ConvAlgo::Raster3x3: ok = ConvRasterEligible(plain, s_in.tile); break;
                     case ConvAlgo::Wino3x3: ok = ConvWinoEligible(plain, s_in.tile); break;
+                    case ConvAlgo::X6: ok = ConvX6Eligible(plain, s_in.tile); break;
                     case ConvAlgo::Stem: ok = ConvStemEligible(a); break;
                     default: break;
                 }
@@ -1113,6 +1164,7 @@ void DeviceModel::LaunchStep(const PlanInstance& pi, const Step& s_in, hipStream
             else if (s.algo == ConvAlgo::Ws3x3) check(LaunchConvWs3x3F16(a, s.tile, stream_), "conv3x3_ws_f16");
             else if (s.algo == ConvAlgo::Stem) check(LaunchConvStem(a, stream_), "conv_stem");
             else if (s.algo == ConvAlgo::Wino3x3) check(LaunchConvWino3x3(a, s.tile, stream_), "conv3x3_wino");
+            else if (s.algo == ConvAlgo::X6) check(LaunchConvX6(a, s.tile, stream_), "conv1x1_x6");
             else if (s.algo == ConvAlgo::Direct) check(LaunchConvDirect(a, s.tile, stream_), "conv_direct");
             else if (s.in.f16) check(LaunchConvIgemmF16(a, s.tile, s.splitk, stream_), "conv_igemm_f16");
             else check(LaunchConvIgemm(a, s.tile, s.algo == ConvAlgo::IgemmVec ? 1 : 0, s.splitk, stream_), "conv_igemm");
@@ -1186,6 +1238,7 @@ static std::string kernel_label(const Step& s) {
             if (s.algo == ConvAlgo::Ws1x1) return std::string(s.in.f16 ? "conv1x1_ws_f16_kernel<t" : "conv1x1_ws_f32_kernel<t") + std::to_string(s.tile) + ">";
             if (s.algo == ConvAlgo::Ws3x3) return "conv3x3_ws_f16_kernel<t" + std::to_string(s.tile) + ">";
             if (s.algo == ConvAlgo::Wino3x3) return "conv3x3_wino_kernel<t" + std::to_string(s.tile) + ">";
+            if (s.algo == ConvAlgo::X6) return "conv1x1_x6_kernel<t" + std::to_string(s.tile) + ">";
             if (s.algo == ConvAlgo::Raster3x3)
                 return "conv3x3_raster_kernel<t" + std::to_string(s.tile) + (s.splitk > 1 ? ",splitk" + std::to_string(s.splitk) : std::string()) + ">";
             return std::string(s.in.f16 ? "conv_igemm_f16_kernel<" : "conv_igemm_kernel<") + std::to_string(kIgemmTiles[s.tile].bm) + "x" +

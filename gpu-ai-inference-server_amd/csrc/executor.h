@@ -47,6 +47,11 @@ struct DeviceWeights {
     float* d_weights_wino = nullptr;
     struct WinoRegion { int64_t w_off, u_off; int cout, cin; };
     std::vector<WinoRegion> wino_regions;
+    // fp32 mode with IE_FP32_SPLIT=1: every eligible 1x1 conv's weights as three bf16 planes in MFMA-fragment order (kernels_x6.hip)
+    void* d_weights_x6 = nullptr;
+    struct X6Region { int64_t w_off, byte_off; int cout, k; };
+    std::vector<X6Region> x6_regions;
+    bool fp32_split = false;
     struct FragRegion { int64_t w_off; int cout, kk, cin; };
     std::vector<FragRegion> frag_regions;
     size_t weight_floats = 0;
@@ -87,6 +92,7 @@ struct DeviceModelOptions {
     std::shared_ptr<DeviceWeights> share;   // lane on a device that already holds the weights
     bool upload_weights = true;             // false: allocate the blob only (an RCCL broadcast fills it, then WeightsArrived())
     std::string tune_cache_path;            // where the kernel-choice cache is persisted ("" = nowhere)
+    bool fp32_split = false;                // fp32 mode: allow the bf16x6 kernels (config.json "fp32_split"; IE_FP32_SPLIT overrides)
 };
 
 class DeviceModel {
@@ -127,6 +133,7 @@ public:
     float* weights() const { return w_->d_weights; }
     const std::shared_ptr<DeviceWeights>& shared_weights() const { return w_; }
     Precision precision() const { return precision_; }
+    bool fp32_split() const { return fp32_split_; }           // fp32 mode with the bf16x6 kernels in the search
     // The fp32 blob was (re)written in place (RCCL broadcast, EngineWeightsUpdated): rebuild the half / fragment-major mirrors.
     void WeightsArrived();
     size_t weight_bytes() const { return w_->weight_floats * sizeof(float); }
@@ -162,6 +169,7 @@ private:
     std::shared_ptr<DeviceWeights> w_;
     bool owns_weights_ = false;
     bool upload_weights_ = true;
+    bool fp32_split_ = false;
     Precision precision_ = Precision::F32;
     size_t device_bytes_ = 0;
     float u8_scale_ = 1.0f / 255.0f, u8_bias_ = 0.0f;

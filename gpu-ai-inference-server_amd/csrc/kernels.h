@@ -129,7 +129,7 @@ hipError_t LaunchConvWino3x3(const ConvArgs& a, int tile, hipStream_t stream);
 hipError_t LaunchWinogradWeights(const float* w, float* u, int Cout, int Cin, hipStream_t stream);
 hipError_t InitKernelsWino();
 // fp32 1x1 conv on the bf16 matrix pipe with exactly split operands (kernels_x6.hip; opt-in, IE_FP32_SPLIT=1): `w16` points at the three
-// bf16 planes LaunchSplitWeightsX6 built from the conv's fp32 weights.  tile 0: 128 pixels per workgroup, 1: 64.
+// bf16 planes LaunchSplitWeightsX6 built from the conv's fp32 weights.  tile 0: 64 pixels per workgroup, 1: 32.
 constexpr int kNumConvX6Tiles = 2;
 bool ConvX6Eligible(const ConvArgs& a, int tile);
 hipError_t LaunchConvX6(const ConvArgs& a, int tile, hipStream_t stream);

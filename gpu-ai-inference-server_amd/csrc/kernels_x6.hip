@@ -9,7 +9,7 @@
 // product.  Measured (scripts/probes/bf16x6_probe.cpp): 198 cycles per 32x32x16 block against 517 for eight fp32 MFMAs (2.17x in time at
 // the clocks each load sustains), max error of a 32x32x1024 product against float64 1.16e-6 of max|C| against 1.07e-6 for the fp32 MFMA.
 //
-// Kernel: a workgroup (4 waves) owns 32 * BMB pixels x 128 output channels; wave w owns the 32 channels of N block w and ALL the
+// Kernel: a workgroup (4 waves) owns 32 * BMB pixels (BMB = 2 or 1) x 128 output channels; wave w owns the 32 channels of N block w and ALL the
 // pixels (BMB accumulator tiles).  The activations go global -> registers (BN+ReLU prologue, split into three bf16 planes: VALU work
 // that co-issues with the bf16 MFMAs) -> LDS in chunks of 32 input channels, double-buffered, one barrier per chunk; the pre-split
 // weights (LaunchSplitWeightsX6, fragment-major: 1 KiB per load) stream from L2 into a register ring one chunk ahead.
@@ -60,7 +60,7 @@ hipError_t LaunchSplitWeightsX6(const float* w, void* dst, int Cout, int K, hipS
 }
 
 template <int BMB, bool PRE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv1x1_x6_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, BMB <= 2 ? 4 : 2))) void conv1x1_x6_kernel(const ConvArgs a) {
     constexpr int NT = 256, BM = 32 * BMB, KC = 32, PITCH = 40;      // LDS row pitch in bf16: 64 B of data + 16 B: the fragment reads are conflict-free
     constexpr int PLANE = BM * PITCH;                                  // bf16 elements per plane per buffer
     constexpr unsigned OOB = 0x80000000u;
@@ -91,12 +91,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto issue_a = [&](f32x4 (&raw)[BMB], int c) {
 #pragma unroll
         for (int u = 0; u < BMB; ++u)
-            raw[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (c < NCH && aoff[u] != OOB) ? aoff[u] + unsigned(c * KC) * 4u : OOB, 0, 0));
+            raw[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, aoff[u], (c < NCH ? c : NCH - 1) * KC * 4, 0));      // past the end: the last chunk again, never consumed
     };
     auto stage_a = [&](const f32x4 (&raw)[BMB], int c, int buf) {
         f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sf = {0.f, 0.f, 0.f, 0.f};
         if constexpr (PRE) {
-            const int cc = c < NCH ? c : 0;
+            const int cc = c < NCH ? c : NCH - 1;
             sc = *reinterpret_cast<const f32x4*>(a.pre_scale + cc * KC + q * 4);
             sf = *reinterpret_cast<const f32x4*>(a.pre_shift + cc * KC + q * 4);
         }
@@ -111,15 +111,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     x = x * sc[e] + sf[e];
                     if (a.pre_relu) x = fmaxf(x, 0.f);
                 }
-                h0[e] = f2u(x) & 0xffff0000u;
-                const float r1 = x - u2f(h0[e]);
-                h1[e] = f2u(r1) & 0xffff0000u;
-                h2[e] = f2u(r1 - u2f(h1[e]));
+                h0[e] = f2u(x);
+                const float r1 = x - u2f(h0[e] & 0xffff0000u);
+                h1[e] = f2u(r1);
+                h2[e] = f2u(r1 - u2f(h1[e] & 0xffff0000u));
             }
-            // pack the high halves: {e0, e1} and {e2, e3}
-            const u32x2 p0 = {(h0[0] >> 16) | h0[1], (h0[2] >> 16) | h0[3]};
-            const u32x2 p1 = {(h1[0] >> 16) | h1[1], (h1[2] >> 16) | h1[3]};
-            const u32x2 p2 = {(h2[0] >> 16) | (h2[1] & 0xffff0000u), (h2[2] >> 16) | (h2[3] & 0xffff0000u)};
+            // pack the high halves of {e0, e1} and {e2, e3}: one v_perm_b32 per pair (bytes 2,3 of the first source low, of the second high)
+            const u32x2 p0 = {__builtin_amdgcn_perm(h0[1], h0[0], 0x07060302u), __builtin_amdgcn_perm(h0[3], h0[2], 0x07060302u)};
+            const u32x2 p1 = {__builtin_amdgcn_perm(h1[1], h1[0], 0x07060302u), __builtin_amdgcn_perm(h1[3], h1[2], 0x07060302u)};
+            const u32x2 p2 = {__builtin_amdgcn_perm(h2[1], h2[0], 0x07060302u), __builtin_amdgcn_perm(h2[3], h2[2], 0x07060302u)};
             unsigned short* const o = base + u * 32 * PITCH;
             *reinterpret_cast<u32x2*>(o) = p0;
             *reinterpret_cast<u32x2*>(o + PLANE) = p1;
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int p = 0; p < 3; ++p)
-                wr[kb][p] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, c < NCH ? unsigned(p) * plane_bytes + unsigned(((nb * KB + 2 * c + kb) * 64 + lane) * 16) : OOB, 0, 0);
+                wr[kb][p] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, unsigned(lane) * 16u, int(unsigned(p) * plane_bytes + unsigned((nb * KB + 2 * (c < NCH ? c : NCH - 1) + kb) * 1024)), 0);
     };
 
     f32x16 acc[BMB];
@@ -168,19 +168,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     stage_a(rawA, 0, 0);
     issue_a(rawA, 2);
     __syncthreads();
-    // two chunks per trip (raw / ring parity); NCH may be odd: the surplus half-trip computes on zero weights (OOB loads)
-    for (int c = 0; c < NCH; c += 2) {
+    // Two chunks per trip (raw / ring parity).  Each half is ONE scheduling region: the MFMAs of the current chunk with the split of
+    // the next one (VALU, co-issues with the bf16 pipe) threaded between them -- a wave issues in order, so without the interleave the
+    // split would only start after the last MFMA had issued.
+    auto interleave = [&]() {
+#pragma unroll
+        for (int i = 0; i < 12 * BMB; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);      // up to six VALU
+        }
+    };
+    int c = 0;
+    for (; c + 1 < NCH; c += 2) {
         issue_w(wB, c + 1);
         compute(wA, 0);
         stage_a(rawB, c + 1, 1);
         issue_a(rawB, c + 3);
+        interleave();
         __syncthreads();
         issue_w(wA, c + 2);
         compute(wB, 1);
         stage_a(rawA, c + 2, 0);
         issue_a(rawA, c + 4);
+        interleave();
         __syncthreads();
     }
+    if (NCH & 1) compute(wA, 0);                        // odd chunk count: the last chunk sits in buffer 0, its weights in wA
 
     // ---- epilogue: lane (channel r of the N block, hh) holds 16 pixel rows of each accumulator tile ----
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out.p, 0, int((int64_t(M - 1) * opitch + Cout) * 4), 0x00020000);
@@ -200,7 +213,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 static size_t x6_lds_bytes(int bmb) { return size_t(2) * 3 * 32 * bmb * 40 * 2; }
 
-// tile 0: 128 pixels per workgroup, tile 1: 64
+// tile 0: 64 pixels per workgroup, tile 1: 32 (128 pixels: 255 VGPRs and no faster than 64 in scripts/probes/x6_probe.cpp)
 bool ConvX6Eligible(const ConvArgs& a, int tile) {
     if (tile < 0 || tile >= kNumConvX6Tiles) return false;
     if (a.in.f16 || a.out.f16 || a.in.f8 || a.out.f8 || a.w16 == nullptr || a.res.p != nullptr) return false;
@@ -229,15 +242,15 @@ hipError_t LaunchConvX6(const ConvArgs& a_in, int tile, hipStream_t stream) {
     if (!ConvX6Eligible(a_in, tile)) return hipErrorInvalidValue;
     ConvArgs a = a_in;
     a.in_bytes = 4 * (int64_t(a.in.n - 1) * a.in.sn + int64_t(a.in.h - 1) * a.in.sh + int64_t(a.in.w - 1) * a.in.sw + a.in.c);
-    return tile == 0 ? launch_x6<4>(a, stream) : launch_x6<2>(a, stream);
+    return tile == 0 ? launch_x6<2>(a, stream) : launch_x6<1>(a, stream);
 }
 
 hipError_t InitKernelsX6() {
     hipError_t e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_x6_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_x6_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_x6_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)) != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_x6_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_x6_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_x6_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)) != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_x6_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
 }
 
 }  // namespace ie

@@ -1027,6 +1027,14 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                         if (direct_ok(t)) { s.algo = ConvAlgo::Direct; s.tile = t; }
                         else if (s.algo == ConvAlgo::Naive && (vec_ok || vec16_ok)) s.algo = ConvAlgo::IgemmVec;
                     }
+                    else if (f == "x6") {
+                        const bool x6_ok = vec_ok && !s.out.f16 && is1x1 && n.sh == 1 && n.sw == 1 && s.in.c % 32 == 0 && N % 128 == 0 && n.res < 0;
+                        if (x6_ok) {
+                            s.algo = ConvAlgo::X6;
+                            s.tile = 0;
+                            if (const char* ft = std::getenv("IE_FORCE_TILE")) { int t = std::atoi(ft); if (t >= 0 && t < 2) s.tile = t; }
+                        }
+                    }
                     else if (f == "wino") {
                         if (wino_ok) {
                             s.algo = ConvAlgo::Wino3x3;
@@ -1044,12 +1052,12 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                             s.algo = (vec_ok || vec16_ok) ? ConvAlgo::IgemmVec : (K <= 2048 && !in16 ? ConvAlgo::IgemmScalar : ConvAlgo::Naive);
                     }
                 }
-                if (const char* ft = (s.algo == ConvAlgo::Raster3x3 || s.algo == ConvAlgo::Ws1x1 || s.algo == ConvAlgo::Ws3x3 || s.algo == ConvAlgo::Stem || s.algo == ConvAlgo::Direct || s.algo == ConvAlgo::Wino3x3) ? nullptr
+                if (const char* ft = (s.algo == ConvAlgo::Raster3x3 || s.algo == ConvAlgo::Ws1x1 || s.algo == ConvAlgo::Ws3x3 || s.algo == ConvAlgo::Stem || s.algo == ConvAlgo::Direct || s.algo == ConvAlgo::Wino3x3 || s.algo == ConvAlgo::X6) ? nullptr
                                                                                                                                           : std::getenv("IE_FORCE_TILE")) {
                     int t = std::atoi(ft);
                     if (t >= 0 && t < kNumIgemmTiles && (t < kNumIgemmBaseTiles || s.algo == ConvAlgo::IgemmVec) && !(in16 && kIgemmTiles[t].deep)) s.tile = t;
                 }
-                if (s.algo != ConvAlgo::IgemmVec && s.algo != ConvAlgo::Raster3x3 && s.algo != ConvAlgo::Ws1x1 && s.algo != ConvAlgo::Ws3x3 && s.algo != ConvAlgo::Direct && s.algo != ConvAlgo::Wino3x3 && s.tile >= kNumIgemmBaseTiles)
+                if (s.algo != ConvAlgo::IgemmVec && s.algo != ConvAlgo::Raster3x3 && s.algo != ConvAlgo::Ws1x1 && s.algo != ConvAlgo::Ws3x3 && s.algo != ConvAlgo::Direct && s.algo != ConvAlgo::Wino3x3 && s.algo != ConvAlgo::X6 && s.tile >= kNumIgemmBaseTiles)
                     s.tile = heuristic_tile;       // K-group tiles exist for the vector path only
                 if (s.algo == ConvAlgo::Raster3x3) {
                     if (const char* fs = std::getenv("IE_FORCE_SPLITK")) {
@@ -1057,7 +1065,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                         if (v >= 1 && v <= 64) s.splitk = v;
                     }
                     if (s.splitk > 1) plan.workspace_floats = std::max<int64_t>(plan.workspace_floats, int64_t(s.splitk) * M * N);
-                } else if (s.algo == ConvAlgo::Ws1x1 || s.algo == ConvAlgo::Ws3x3 || s.algo == ConvAlgo::Stem || s.algo == ConvAlgo::Direct || s.algo == ConvAlgo::Wino3x3) {
+                } else if (s.algo == ConvAlgo::Ws1x1 || s.algo == ConvAlgo::Ws3x3 || s.algo == ConvAlgo::Stem || s.algo == ConvAlgo::Direct || s.algo == ConvAlgo::Wino3x3 || s.algo == ConvAlgo::X6) {
                     s.splitk = 1;
                 } else if (s.algo != ConvAlgo::Naive) {
                     // split-K when the output grid cannot fill the chip: aim for >= ~768 workgroups, keep >= 2 K-tiles
@@ -1240,7 +1248,7 @@ static std::string json_escape(const std::string& s) {
 
 std::string PlanToJson(const Plan& p) {
     static const char* kinds[] = {"conv", "pool", "gap", "eltwise", "copy"};
-    static const char* algos[] = {"igemm_vec", "igemm_scalar", "naive", "raster3x3", "ws1x1", "ws3x3", "stem", "direct", "igemm_f8", "dense_fused", "wino3x3"};
+    static const char* algos[] = {"igemm_vec", "igemm_scalar", "naive", "raster3x3", "ws1x1", "ws3x3", "stem", "direct", "igemm_f8", "dense_fused", "wino3x3", "conv1x1_x6"};
     std::ostringstream o;
     o.precision(17);
     o << "{\"inputs\":[";

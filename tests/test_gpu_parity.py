@@ -1544,6 +1544,72 @@ def test_fused_dense_layer_kernel(tmp_path, batch, image, blocks, fuse_tile):
     assert e < RTOL and e0 < RTOL and rel_err(y, y0) < 2e-5
 
 
+def test_fp32_split_densenet121_full_size(densenet_repo):
+    """BASELINE configs[1] (DenseNet-121, batch 32) with IE_FP32_SPLIT=1: the search may give the 128-channel 1x1 convs to the bf16x6
+    kernel.  Same contract as the native fp32 path: the float64 fixture at B=2 and the float64 oracle on two images of the B=32 batch
+    within RTOL, an error no worse than the native kernels' (x3 slack for summation order), and batch independence."""
+    path = os.path.join(densenet_repo, "densenet_onnx", "1")
+    g = np.load(os.path.join(GOLD, "densenet121_b2.npz"))
+    x2 = models.synthetic_input((2, 3, 224, 224))
+    x32 = models.synthetic_input((32, 3, 224, 224), stream="b32")
+
+    def run():
+        m = B.CreateModel(path, "densenet_onnx")
+        try:
+            y2 = infer(m, "", "data_0", x2, "fc6_1", [2, 1000, 1, 1])[0].reshape(2, 1000).copy()
+            y32 = infer(m, "", "data_0", x32, "fc6_1", [32, 1000, 1, 1])[0].reshape(32, 1000).copy()
+            y1 = infer(m, "", "data_0", x32[31:32], "fc6_1", [1, 1000, 1, 1])[0].reshape(1000).copy()
+            din, _ = B.Prepare(m, [[32, 3, 224, 224]], 1)
+            B.CopyToDevice(m, din[0], x32)
+            B.RunPrepared(m, 2, True)
+            kernels = [p_["kernel"] for p_ in B.Profile(m, 2)]
+            return y2, y32, y1, kernels
+        finally:
+            m.Destroy()
+    y2, y32, y1, kern = _run_with_env(dict(IE_FP32_SPLIT="1", IE_TUNE_CACHE="0", IE_TUNE_BATCHES="2,32"), run)      # the search runs at load, never in a request
+    n2, n32, _, kern0 = _run_with_env(dict(IE_TUNE_CACHE="0", IE_TUNE_BATCHES="2,32"), run)
+    nx = sum(k.startswith("conv1x1_x6_kernel") for k in kern)
+    assert nx >= 12 and not any(k.startswith("conv1x1_x6_kernel") for k in kern0), (nx, kern)
+    e, e0 = rel_err(y2, g["logits_f64"]), rel_err(n2, g["logits_f64"])
+    om = O.load_model(models.densenet121(2))
+    yo = O.run(om, {"data_0": x32[[3, 27]]})["fc6_1"].reshape(2, 1000)
+    f, f0 = rel_err(y32[[3, 27]], yo), rel_err(n32[[3, 27]], yo)
+    print(f"fp32 split: {nx} bf16x6 launches per forward; B=2 vs float64 fixture {e:.2e} (native {e0:.2e}); B=32 images vs oracle {f:.2e} (native {f0:.2e})")
+    assert e < RTOL and f < RTOL and e < 3 * e0 + 1e-7 and f < 3 * f0 + 1e-7
+    assert np.argmax(y2, 1).tolist() == np.argmax(g["logits_f64"], 1).tolist()
+    assert rel_err(y1, y32[31]) < 2e-5 and rel_err(y32, n32) < 2e-5
+
+
+@pytest.mark.parametrize("tile", [0, 1])
+@pytest.mark.parametrize("batch,image,blocks", [(3, 64, (2, 2)), (2, 112, (3,)), (5, 48, (2, 1))])
+def test_bf16x6_1x1_kernel(tmp_path, tile, batch, image, blocks):
+    """conv1x1_x6_kernel (fp32 products from exactly split bf16 operands, six bf16 MFMAs per block; opt-in IE_FP32_SPLIT=1) forced onto
+    every 128-output-channel 1x1 conv of DenseNet-shaped graphs (K = 64 .. 160: even and odd chunk counts, BN+ReLU prologues, ragged
+    pixel tiles), both workgroup tiles, against the float64 oracle at the SAME bound as the native fp32 kernels, and against them."""
+    mb = models.densenet(batch, growth=32, blocks=blocks, stem=64, image=image, classes=12, seed=43)
+    path = models.write_repo(str(tmp_path), "x6", mb)
+    x = models.synthetic_input((batch, 3, image, image), stream="x6")
+    ref = O.run(O.load_model(mb), {"data_0": x}, dtype=np.float64)["fc6_1"]
+
+    def go():
+        plan = B.DescribeModel(path, batch)["plan"]
+        m = B.CreateModel(path, "x6")
+        try:
+            y = infer(m, "", "data_0", x, "fc6_1", [batch, 12, 1, 1])[0].copy()
+            y2 = infer(m, "", "data_0", x, "fc6_1", [batch, 12, 1, 1])[0]
+        finally:
+            m.Destroy()
+        np.testing.assert_array_equal(y, y2)
+        return plan, y
+    plan, y = _run_with_env(dict(IE_FP32_SPLIT="1", IE_FORCE_ALGO="x6", IE_FORCE_TILE=str(tile)), go)
+    nx = [s for s in plan["steps"] if s.get("algo") == "conv1x1_x6"]
+    assert len(nx) >= sum(blocks) and all(s["out"]["c"] % 128 == 0 and s["k"] == [1, 1] for s in nx)
+    _, y0 = _run_with_env(dict(IE_AUTOTUNE="0"), go)
+    e, e0 = rel_err(y, ref), rel_err(y0, ref)
+    print(f"bf16x6 tile {tile} B={batch} image={image}: {len(nx)} convs, rel err {e:.2e} (native fp32 kernels {e0:.2e})")
+    assert e < RTOL and e < 3 * e0 + 1e-7 and rel_err(y, y0) < 2e-5
+
+
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("batch,image,blocks", [(3, 64, (2, 2)), (2, 112, (3,)), (5, 48, (2, 1))])
 def test_winograd_3x3_kernel(tmp_path, tile, batch, image, blocks):
