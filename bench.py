@@ -206,7 +206,7 @@ def measure(B, models, sharding, *, model_name, dtype, Bsz, steps, warmup, rank,
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
         traffic, traffic_src = None, None
         try:      # HBM bytes per launch from the committed PMC pass of the same command (rocprofv3 cannot run inside bench.py)
-            tf = {("densenet121", "f32"): "traffic.json", ("densenet121", "f16"): "traffic_f16_b128.json", ("resnet50", "f8"): "traffic_resnet50_f8_b256.json"}.get((model_name, dtype))
+            tf = {("densenet121", "f32"): "traffic.json", ("densenet121", "f16"): "traffic_f16_b128.json", ("resnet50", "f8"): "traffic_resnet50_f8_b256.json", ("densenet121", "f32x6"): "traffic_f32x6_b32.json"}.get((model_name, dtype))
             rounds = sorted(r_ for r_ in os.listdir(os.path.join(ROOT, "profiles")) if tf and os.path.exists(os.path.join(ROOT, "profiles", r_, tf)))
             if rounds:
                 traffic_src = os.path.join("profiles", rounds[-1], tf)

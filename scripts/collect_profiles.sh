@@ -1,31 +1,34 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun): bench + rocprofv3 kernel trace + separate PMC passes -> gpurun_out/<round>/
 #   fp32 batch 32 DenseNet-121 (the headline, BASELINE configs[1]), fp16 batch 128 (configs[2]), ResNet-50 fp8 batch 256 (configs[4]).
-#   PMC passes never combine with tracing domains.  Every traced / counted run replays the captured hipGraph, like the benchmark
-#   (set IE_PROFILE_EAGER=1 to trace eager launches of the same plan instead).
+#   plus the opt-in fp32 + bf16x6 configuration (batch 32).  PMC passes never combine with tracing domains.  Traced / counted runs launch
+#   the plan's kernels eagerly (same kernels, same durations): hipGraphLaunch under rocprofv3 segfaults intermittently on this ROCm
+#   (profiles/r02/graph_burst_under_kernel_trace_sigsegv.log); IE_PROFILE_GRAPH=1 traces the graph replays instead.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/${1:-r02}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export IE_TUNE_CACHE=$OUT/tune_cache.txt
-[ -n "$IE_PROFILE_EAGER" ] && export IE_DISABLE_GRAPH=1
+TRACE_ENV="IE_DISABLE_GRAPH=1"
+[ -n "$IE_PROFILE_GRAPH" ] && TRACE_ENV="IE_DISABLE_GRAPH=0"
 ROUND=$(basename $OUT)
 python3 $R/scripts/profile_steps.py 32 > $OUT/steps_b32.txt 2>&1
 IE_PRECISION=fp16 python3 $R/scripts/profile_steps.py 128 > $OUT/steps_f16_b128.txt 2>&1
 IE_PRECISION=fp8 python3 $R/scripts/profile_steps.py 256 resnet50 > $OUT/steps_resnet50_f8_b256.txt 2>&1
+IE_FP32_SPLIT=1 python3 $R/scripts/profile_steps.py 32 > $OUT/steps_f32x6_b32.txt 2>&1
 echo "step tables done"
 # name | bench arguments | file suffix
-CONFIGS=("f32|--model densenet121 --dtype f32 --batch 32|" "f16|--model densenet121 --dtype f16 --batch 128|_f16_b128" "r50f8|--model resnet50 --dtype f8 --batch 256|_resnet50_f8_b256")
+CONFIGS=("f32|--model densenet121 --dtype f32 --batch 32|" "f16|--model densenet121 --dtype f16 --batch 128|_f16_b128" "r50f8|--model resnet50 --dtype f8 --batch 256|_resnet50_f8_b256" "f32x6|--model densenet121 --dtype f32x6 --batch 32|_f32x6_b32")
 for CFG in "${CONFIGS[@]}"; do
   IFS="|" read -r NAME ARGS SUF <<< "$CFG"
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$NAME -- python3 $R/bench.py --steps 50 --warmup 10 --cpu-sample 0 --no-hostpath --no-secondary $ARGS > $OUT/rocprof_kernel_trace$SUF.log 2>&1
+  env $TRACE_ENV rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$NAME -- python3 $R/bench.py --steps 50 --warmup 10 --cpu-sample 0 --no-hostpath --no-secondary $ARGS > $OUT/rocprof_kernel_trace$SUF.log 2>&1
   echo "kernel trace $NAME rc=$?"
   cp $OUT/kt_$NAME/*/*_kernel_stats.csv $OUT/kernel_stats$SUF.csv 2>/dev/null
   rm -rf $OUT/kt_$NAME
   for C in "FETCH_SIZE TCC_HIT_sum" "WRITE_SIZE TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
     N=$(echo $C | cut -d" " -f1)
-    rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_${NAME}_$N -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-hostpath --no-secondary $ARGS > $OUT/pmc_$N$SUF.log 2>&1 || echo "PMC pass $N ($NAME) failed"
+    env $TRACE_ENV rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_${NAME}_$N -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-hostpath --no-secondary $ARGS > $OUT/pmc_$N$SUF.log 2>&1 || echo "PMC pass $N ($NAME) failed"
     python3 $R/scripts/pmc_summary.py $OUT/pmc_${NAME}_$N > $OUT/pmc_$N$SUF.summary.csv
     rm -rf $OUT/pmc_${NAME}_$N
   done
