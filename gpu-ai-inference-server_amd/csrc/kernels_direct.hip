@@ -430,12 +430,16 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_as_kernel(const ConvArgs a
     // ---- weight ring: chunk c of 16-channel block nb is the KiB at ((nb * CH + c) * 64 + lane) * 16 ----
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wfrag), 0, Cout * K * 4, 0x00020000);
     const int nb = n0 >> 4;
+    // fp32 MFMAs and VALU instructions do not overlap on this part: the K loop carries no vector address arithmetic.
+    // Weight loads: lane * 16 in the VGPR, everything else in the scalar offset; past the last chunk the last chunk is loaded again
+    // (in range, never consumed).  Fragment reads: one base per pixel block, bumped once per ring trip, chunk = immediate offset.
     u32x4 ring[D][TNW];
     int c_l = 0;
+    const unsigned wlane = unsigned(lane) * 16u;
     auto issue = [&](int slot) {
+        const int c = c_l < CH ? c_l : CH - 1;
 #pragma unroll
-        for (int j = 0; j < TNW; ++j)
-            ring[slot][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, c_l < CH ? unsigned(((nb + j) * CH + c_l) * 64 + lane) * 16u : OOB, 0, 0);
+        for (int j = 0; j < TNW; ++j) ring[slot][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, ((nb + j) * CH + c) * 1024, 0);
         ++c_l;
     };
 #pragma unroll
@@ -483,20 +487,21 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_as_kernel(const ConvArgs a
     for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
         for (int j = 0; j < TNW; ++j) acc[pb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int c_c = 0;
-    const float* const arow = sA + r * P + gk * 4;
+    const float* abase[PB];                            // this lane's fragment address in each pixel block, at the current ring trip
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) abase[pb] = sA + (pb * 16 + r) * P + gk * 4;
     // activation fragments are read one chunk ahead of the MFMAs that consume them (the LDS latency hides behind 4*PB*TNW MFMAs
-    // instead of stalling every chunk; the scheduler otherwise sinks each read to its use)
+    // instead of stalling every chunk; the scheduler otherwise sinks each read to its use).  The read ahead of the last chunk runs
+    // 16 floats past K: the row's pad and the head of the next row (the launcher allocates 64 bytes behind the last row).
     f32x4 avn[PB];
 #pragma unroll
-    for (int pb = 0; pb < PB; ++pb) avn[pb] = *reinterpret_cast<const f32x4*>(arow + pb * 16 * P);
-    auto compute = [&](int slot) {
+    for (int pb = 0; pb < PB; ++pb) avn[pb] = *reinterpret_cast<const f32x4*>(abase[pb]);
+    auto compute = [&](int slot) {                     // slot = chunk index within the ring trip: the next chunk sits (slot + 1) * 16 floats on
         f32x4 av[PB];
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) av[pb] = avn[pb];
-        const float* const nxt = arow + (c_c + 1 < CH ? c_c + 1 : c_c) * 16;
 #pragma unroll
-        for (int pb = 0; pb < PB; ++pb) avn[pb] = *reinterpret_cast<const f32x4*>(nxt + pb * 16 * P);
+        for (int pb = 0; pb < PB; ++pb) avn[pb] = *reinterpret_cast<const f32x4*>(abase[pb] + (slot + 1) * 16);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -506,7 +511,6 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_as_kernel(const ConvArgs a
                     acc[pb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(f32x4, ring[slot][j])[e], av[pb][e], acc[pb][j], 0, 0, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, PB, 0);                 // next chunk's fragment reads first ...
         __builtin_amdgcn_sched_group_barrier(0x008, 4 * PB * TNW, 0);       // ... then this chunk's MFMAs
-        ++c_c;
     };
     const int full = CH / D, rem = CH - full * D;
     for (int it = 0; it < full; ++it) {
@@ -515,6 +519,8 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_as_kernel(const ConvArgs a
             compute(s);
             issue(s);
         }
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) abase[pb] += D * 16;
     }
 #pragma unroll
     for (int s = 0; s < D; ++s)
@@ -560,7 +566,7 @@ static bool as_eligible(const ConvArgs& a, int at) {
     const int64_t M = int64_t(a.out.n) * a.out.h * a.out.w;
     if (M > (int64_t(1) << 22) || M * a.in.sw * 4 >= (int64_t(1) << 31) || M * a.out.sw * 4 >= (int64_t(1) << 31) || int64_t(a.out.c) * a.in.c * 4 >= (int64_t(1) << 31))
         return false;
-    return size_t(16 * t.pb) * (a.in.c + 8) * 4 <= size_t(160) * 1024;
+    return size_t(16 * t.pb) * (a.in.c + 8) * 4 + 64 <= size_t(160) * 1024;
 }
 
 template <int AT>
@@ -576,7 +582,7 @@ static hipError_t launch_as_t(const ConvArgs& a_in, hipStream_t stream) {
     a.debug = pad << 8;
     const int64_t M = int64_t(a.out.n) * a.out.h * a.out.w;
     const dim3 grid(unsigned((M + 16 * t.pb - 1) / (16 * t.pb)), unsigned(a.out.c / (16 * t.tnw * t.waves)));
-    const size_t lds = size_t(16 * t.pb) * (a.in.c + pad) * 4;
+    const size_t lds = size_t(16 * t.pb) * (a.in.c + pad) * 4 + 64;      // + the read-ahead past the last row
     if (lds > size_t(160) * 1024) return hipErrorInvalidValue;
     if (a.pre_scale) conv1x1_as_kernel<t.waves, t.tnw, t.pb, true><<<grid, dim3(64 * t.waves), lds, stream>>>(a);
     else conv1x1_as_kernel<t.waves, t.tnw, t.pb, false><<<grid, dim3(64 * t.waves), lds, stream>>>(a);

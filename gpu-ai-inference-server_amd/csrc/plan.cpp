@@ -11,6 +11,12 @@
 #include "igemm_tiles.h"
 
 namespace ie {
+
+// Dense-layer fusion applies where launches are latency-bound: up to this many output pixels (IE_FUSE_MAX_M overrides; A/B switch).
+static int64_t FuseMaxPixels() {
+    static const int64_t v = [] { const char* e = std::getenv("IE_FUSE_MAX_M"); const long long x = e ? std::atoll(e) : 0; return x > 0 ? int64_t(x) : int64_t(8192); }();
+    return v;
+}
 namespace {
 
 [[noreturn]] void fail(const std::string& msg) { throw std::runtime_error(msg); }
@@ -762,7 +768,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
             const LNode& b1 = L.nodes[order[nxt]];
             if (a3.kind != L_CONV || b1.kind != L_CONV || a3.kh != 3 || a3.kw != 3 || b1.kh != 1 || b1.kw != 1 || a3.has_pre) continue;
             if (L.vals[a3.out].c != 32 || L.vals[b1.out].c != 128 || L.vals[b1.in[0]].root != L.vals[a3.out].root) continue;
-            if (L.vals[a3.out].n * L.vals[a3.out].h * L.vals[a3.out].w > 8192) continue;
+            if (L.vals[a3.out].n * L.vals[a3.out].h * L.vals[a3.out].w > FuseMaxPixels()) continue;
             const int rb = L.vals[a3.in[0]].root;
             last_use[rb] = std::max(last_use[rb], int(nxt));
         }
@@ -1160,16 +1166,16 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                        9 * (s3.in.c / 16) >= 8 && s1.kh == 1 && s1.kw == 1 && s1.sh == 1 && s1.sw == 1 && s1.pt == 0 && s1.pl == 0 && s1.pb == 0 && s1.pr == 0 &&
                        !s1.has_in2 && s1.out.c == 128 && s1.in.buf == s3.out.buf && s1.in.pitch == s3.out.pitch && !s1.in.nchw && !s3.in.nchw &&
                        s1.in.c_off + s1.in.c == s3.out.c_off + s3.out.c && s1.in.c >= 48 && s1.in.c % 16 == 0 && s1.in.n == s3.out.n && s1.in.h == s3.out.h &&
-                       s1.in.w == s3.out.w && s1.out.buf != s3.in.buf && M <= 8192 && s3.algo != ConvAlgo::Naive && s1.algo != ConvAlgo::Naive &&
+                       s1.in.w == s3.out.w && s1.out.buf != s3.in.buf && M <= FuseMaxPixels() && s3.algo != ConvAlgo::Naive && s1.algo != ConvAlgo::Naive &&
                        s3.in.pitch % 4 == 0 && s3.in.c_off % 4 == 0 && s1.in.pitch % 4 == 0 && s1.in.c_off % 4 == 0 && s1.out.pitch % 4 == 0 && s1.out.c_off % 4 == 0;
                 if (fuse) {
                     int pb = M <= 2048 ? 1 : 2;
                     int ftile = 0;
                     if (const char* e = std::getenv("IE_FUSE_PB")) { const int v = std::atoi(e); if (v == 1 || v == 2) pb = v; if (v == 3) { pb = 1; ftile = 3; } if (v == 4 || v == 5) { pb = v - 3; ftile = v; } }
                     const int64_t px = 16 * pb;
-                    const int64_t win = (px + 2 * s3.in.w + 2) * (s3.in.c + 4) * 4, part = 4 * px * 36 * 4;
+                    const int64_t win = (px + 2 * s3.in.w + 2) * (s3.in.c + 8) * 4, part = 4 * px * 36 * 4;
                     const int64_t c4n = (s1.in.c - 32) / 4, rpp = c4n > 0 && c4n <= 512 ? 512 / c4n : 0;
-                    if (std::max(px * (s1.in.c + 4) * 4, win) + part > 160 * 1024 || rpp == 0 || (px + rpp - 1) / rpp > (pb == 1 ? 8 : 16) ||
+                    if (std::max(px * (s1.in.c + 8) * 4, win) + part > 160 * 1024 || rpp == 0 || (px + rpp - 1) / rpp > (pb == 1 ? 8 : 16) ||
                         (px + 2 * s3.in.w + 2) * (s3.in.c / 4) > 8 * 512)
                         fuse = false;
                     if (fuse) {
