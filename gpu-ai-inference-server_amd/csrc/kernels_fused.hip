@@ -176,7 +176,8 @@ void conv_dense_fused_kernel(const ConvArgs a, const FusedArgs f, const int part
     u32x4 ring[D];
     int c_l = 0;
     auto issue = [&](int slot) {
-        ring[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (c_l < CH && !(a.debug & 16)) ? unsigned((wave * CH + c_l) * 64 + lane) * 16u : OOB, 0, 0);
+        // lane * 16 in the VGPR, the rest scalar; past the last chunk the last one again (in range, never consumed): no VALU in the K loop
+        ring[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (a.debug & 16) ? OOB : unsigned(lane) * 16u, (wave * CH + (c_l < CH ? c_l : CH - 1)) * 1024, 0);
         ++c_l;
     };
 #pragma unroll
@@ -253,18 +254,18 @@ void conv_dense_fused_kernel(const ConvArgs a, const FusedArgs f, const int part
     f32x4 acc[PB];
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) acc[pb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int c_c = 0;
-    const float* const arow = sA + r * P + gk * 4;
+    const float* abase[PB];                            // fragment address per pixel block at the current ring trip; chunk = immediate offset
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) abase[pb] = sA + (pb * 16 + r) * P + gk * 4;
     f32x4 avn[PB];
 #pragma unroll
-    for (int pb = 0; pb < PB; ++pb) avn[pb] = *reinterpret_cast<const f32x4*>(arow + pb * 16 * P);
-    auto compute = [&](int slot) {
+    for (int pb = 0; pb < PB; ++pb) avn[pb] = *reinterpret_cast<const f32x4*>(abase[pb]);
+    auto compute = [&](int slot) {                     // the read ahead of the last chunk runs 16 floats past K (pad + next row / the partial tiles)
         f32x4 av[PB];
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) av[pb] = avn[pb];
-        const float* const nxt = arow + (c_c + 1 < CH ? c_c + 1 : c_c) * 16;
 #pragma unroll
-        for (int pb = 0; pb < PB; ++pb) avn[pb] = *reinterpret_cast<const f32x4*>(nxt + pb * 16 * P);
+        for (int pb = 0; pb < PB; ++pb) avn[pb] = *reinterpret_cast<const f32x4*>(abase[pb] + (slot + 1) * 16);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -272,7 +273,6 @@ void conv_dense_fused_kernel(const ConvArgs a, const FusedArgs f, const int part
                 acc[pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(f32x4, ring[slot])[e], av[pb][e], acc[pb], 0, 0, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, PB, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 4 * PB, 0);
-        ++c_c;
     };
     const int full = (a.debug & 2) ? 0 : CH / D, rem = (a.debug & 2) ? 0 : CH - (CH / D) * D;
     for (int it = 0; it < full; ++it) {
@@ -281,6 +281,8 @@ void conv_dense_fused_kernel(const ConvArgs a, const FusedArgs f, const int part
             compute(s);
             issue(s);
         }
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) abase[pb] += D * 16;
     }
 #pragma unroll
     for (int s = 0; s < D; ++s)
