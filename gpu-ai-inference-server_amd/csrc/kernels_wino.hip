@@ -124,20 +124,29 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, W
         }
         woff[i] = off;
     }
+    // fp32 MFMAs and VALU instructions do not overlap: the K loop carries no vector address arithmetic.  Loads: the lane's
+    // part of the address in a VGPR fixed before the loop, slice / stage in the scalar offset (past the end: the last one again, in
+    // range and never consumed; a lane outside the image keeps its out-of-range marker whatever the scalar offset says).
+    unsigned wvo[PITW];
+    float* wlds[2][PITW];
+#pragma unroll
+    for (int i = 0; i < PITW; ++i) {
+        const int it = tid + i * NT;
+        wvo[i] = woff[i] >= 0 ? unsigned(woff[i]) * 4u : OOB;
+#pragma unroll
+        for (int bf = 0; bf < 2; ++bf) wlds[bf][i] = sWin + bf * win_floats + (it >> 2) * LP + (it & 3) * 4;
+    }
     f32x4 pvA[PITW], pvB[PITW];                         // windows in flight: even / odd slices
     const int nslices = Cin / CS, nstages = 2 * nslices;
     auto issue_window = [&](f32x4 (&pv)[PITW], int s) {
 #pragma unroll
         for (int i = 0; i < PITW; ++i)
-            pv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (woff[i] >= 0 && s < nslices) ? unsigned(woff[i] + s * CS) * 4u : OOB, 0, 0));
+            pv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, wvo[i], (s < nslices ? s : nslices - 1) * CS * 4, 0));
     };
     auto commit_window = [&](const f32x4 (&pv)[PITW], int buf) {
-        float* const w = sWin + buf * win_floats;
 #pragma unroll
-        for (int i = 0; i < PITW; ++i) {
-            const int it = tid + i * NT;
-            if (it < items) *reinterpret_cast<f32x4*>(w + (it >> 2) * LP + (it & 3) * 4) = pv[i];
-        }
+        for (int i = 0; i < PITW; ++i)
+            if (tid + i * NT < items) *reinterpret_cast<f32x4*>(wlds[buf][i]) = pv[i];
     };
     // Row i of the transformed tile: m_c = d[ra][c] + sg * d[rb][c] with (ra, rb, sg) = (0,2,-), (1,2,+), (2,1,-), (1,3,-).
     const int wi = wave / (WAVES / 4), jh = wave % (WAVES / 4);       // this wave's row and (8 waves) its pair of columns
@@ -153,15 +162,16 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, W
     auto issue_u = [&](u32x4 (&ub)[NJ], int h) {
 #pragma unroll
         for (int xl = 0; xl < NJ; ++xl)
-            ub[xl] = __builtin_amdgcn_raw_buffer_load_b128(rs_u, h < nstages ? unsigned(((NJ * wave + xl) * c8n + h) * 64 + lane) * 16u : OOB, 0, 0);
+            ub[xl] = __builtin_amdgcn_raw_buffer_load_b128(rs_u, unsigned(lane) * 16u, ((NJ * wave + xl) * c8n + (h < nstages ? h : nstages - 1)) * 1024, 0);
     };
     f32x4 dra[NC], drb[NC];                             // window rows ra / rb, the wave's columns, this lane's four channels
-    auto read_d = [&](int buf, int half) {
-        const float* const w = sWin + buf * win_floats + half * 8;
+    const float* const pdA[2] = {sWin + dA, sWin + win_floats + dA};
+    const float* const pdB[2] = {sWin + dB, sWin + win_floats + dB};
+    auto read_d = [&](int buf, int half) {             // buf and half are compile-time at every call: immediate offsets only
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            dra[c] = *reinterpret_cast<const f32x4*>(w + dA + c * LP);
-            drb[c] = *reinterpret_cast<const f32x4*>(w + dB + c * LP);
+            dra[c] = *reinterpret_cast<const f32x4*>(pdA[buf] + half * 8 + c * LP);
+            drb[c] = *reinterpret_cast<const f32x4*>(pdB[buf] + half * 8 + c * LP);
         }
     };
     f32x4 af[NJ];                                       // A fragments of the next stage: V[wi][j], four channels
