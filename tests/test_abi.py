@@ -155,7 +155,7 @@ def test_config_json_is_parsed_not_scraped(tmp_path):
       "inputs": [{"name": "x", "dims": [64, 1, 1], "shape": [4, 64, 1, 1], "data_type": "FLOAT32", "gpus": 8, "precision": "fp16"}],
       "outputs": [{"name": "y", "dims": [10], "shape": [4, 10], "data_type": "FLOAT32", "label_filename": "labels \"gpus\": 7 .txt"}],
       "notes": "\"gpus\": 6, \"precision\": \"fp16\", \"dynamic_batching\": true, \"max_batch_size\": 64",
-      "nested": {"gpus": 5, "instance_count": 9, "uint8_scale": 3.0, "dynamic_batching": true, "max_batch_size": 32},
+      "nested": {"gpus": 5, "instance_count": 9, "uint8_scale": 3.0, "dynamic_batching": true, "max_batch_size": 32, "fp32_split": true},
       "uint8_bias": -1.5e0, "instance_count": 2, "tune_batches": [1, 8], "unicode": "é😀"
     }'''
     path = models.write_repo(str(tmp_path), "decoy", models.gemm_mlp("N"), config_json=cfg)
@@ -163,13 +163,15 @@ def test_config_json_is_parsed_not_scraped(tmp_path):
     assert c["present"] and (c["name"], c["platform"], c["version"]) == ("decoy", "onnxruntime_onnx", "1")
     assert c["gpus"] == 0 and c["precision"] == "" and not c["dynamic_batching"] and c["max_batch_size"] == 0
     assert abs(c["uint8_scale"] - 1 / 255) < 1e-7 and c["uint8_bias"] == -1.5 and c["instance_count"] == 2 and c["tune_batches"] == [1, 8]
+    assert c["fp32_split"] is False                       # the nested one does not count
     assert c["inputs"] == [{"name": "x", "data_type": "FLOAT32", "label_filename": "", "dims": [64, 1, 1], "shape": [4, 64, 1, 1]}]
     assert c["outputs"][0]["label_filename"] == 'labels "gpus": 7 .txt' and c["outputs"][0]["shape"] == [4, 10]
     # top-level keys are honoured
     path2 = models.write_repo(str(tmp_path), "real", models.gemm_mlp("N"),
-                              config_json='{"gpus": 4, "precision": "FP16", "dynamic_batching": true, "max_batch_size": 16, "batch_window_us": 50}')
+                              config_json='{"gpus": 4, "precision": "FP16", "dynamic_batching": true, "max_batch_size": 16, "batch_window_us": 50, "fp32_split": true}')
     c2 = B.DescribeModel(path2)["config"]
     assert (c2["gpus"], c2["precision"], c2["dynamic_batching"], c2["max_batch_size"], c2["batch_window_us"]) == (4, "fp16", True, 16, 50)
+    assert c2["fp32_split"] is True
     # no file: defaults; malformed file: an error that names the position, not a silent default
     path3 = models.write_repo(str(tmp_path), "nocfg", models.gemm_mlp("N"))
     assert B.DescribeModel(path3)["config"]["present"] is False
