@@ -66,12 +66,23 @@ void conv_dense_fused_kernel(const ConvArgs a, const FusedArgs f, const int part
     const int items3 = npx * c4n3;
     constexpr int MAXW = 8;                            // window slots per thread: items3 <= MAXW * NT (checked by the launcher)
     u32x4 wv[MAXW];
+    // (row, 4-channel column) of slot u = (tid + u * NT) / c4n3: ONE division, then scalar strides with a carry -- an fp32 kernel pays
+    // for VALU instructions in MFMA slots and this workgroup is alone on its CU
+    const int wq = NT / c4n3, wr = NT - wq * c4n3;     // wave-uniform
+    int wrow[MAXW], wc4[MAXW];
+    wrow[0] = tid / c4n3;
+    wc4[0] = tid - wrow[0] * c4n3;
+#pragma unroll
+    for (int u = 1; u < MAXW; ++u) {
+        const int c = wc4[u - 1] + wr;
+        const bool carry = c >= c4n3;
+        wc4[u] = carry ? c - c4n3 : c;
+        wrow[u] = wrow[u - 1] + wq + (carry ? 1 : 0);
+    }
 #pragma unroll
     for (int u = 0; u < MAXW; ++u) {
-        const int idx = tid + u * NT;
-        const int row = idx / c4n3, c4 = idx - row * c4n3;
-        const int p = p_lo + row;
-        wv[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (idx < items3 && p >= 0 && p < M) ? unsigned(p * bpitch + c4 * 4) * 4u : OOB, 0, 0);
+        const int p = p_lo + wrow[u];
+        wv[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (wrow[u] < npx && p >= 0 && p < M) ? unsigned(p * bpitch + wc4[u] * 4) * 4u : OOB, 0, 0);
     }
 
     // ---- (b) the 3x3's weight fragments of this wave's K slice (fragment-major: 1 KiB per load) ----
@@ -122,13 +133,8 @@ void conv_dense_fused_kernel(const ConvArgs a, const FusedArgs f, const int part
 
     // ---- (d) window -> LDS ----
 #pragma unroll
-    for (int u = 0; u < MAXW; ++u) {
-        const int idx = tid + u * NT;
-        if (idx < items3) {
-            const int row = idx / c4n3, c4 = idx - row * c4n3;
-            *reinterpret_cast<u32x4*>(sWin + row * P3 + c4 * 4) = wv[u];
-        }
-    }
+    for (int u = 0; u < MAXW; ++u)
+        if (wrow[u] < npx) *reinterpret_cast<u32x4*>(sWin + wrow[u] * P3 + wc4[u] * 4) = wv[u];
     __syncthreads();
 
     // ---- (e) 3x3 on 16 x 16 x 4 tiles: lane (r, gk) owns pixel r of each pixel block ----
@@ -145,18 +151,29 @@ void conv_dense_fused_kernel(const ConvArgs a, const FusedArgs f, const int part
 #pragma unroll
         for (int j = 0; j < TN3; ++j) acc3[pb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // which of the nine taps fall inside the image for this lane's pixel: one bit each, tested in the chunk loop with a shift
+    unsigned tapmask[PB];
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+        unsigned mk = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            if (mok[pb] && unsigned(oy[pb] + t / 3 - 1) < unsigned(H) && unsigned(ox[pb] + t % 3 - 1) < unsigned(W)) mk |= 1u << t;
+        tapmask[pb] = mk;
+    }
+    const float* const wlane = sWin + r * P3 + gk * 4;
 #pragma unroll
     for (int i = 0; i < MAXC3; ++i) {
         if (cb + i < ce && !(a.debug & 1)) {           // wave-uniform (debug bits: timing-only ablations, wrong results)
             const int ch = cb + i;
             const int tap = ch / cpt3, c0 = (ch - tap * cpt3) * 16;
             const int ky = tap / 3, kx = tap - ky * 3;
+            const float* const wtap = wlane + (ky * W + kx) * P3 + c0;      // scalar offset on a loop-invariant lane address
             f32x4 av[PB];
 #pragma unroll
             for (int pb = 0; pb < PB; ++pb) {
-                const bool ok = mok[pb] && unsigned(oy[pb] + ky - 1) < unsigned(H) && unsigned(ox[pb] + kx - 1) < unsigned(W);
-                av[pb] = *reinterpret_cast<const f32x4*>(sWin + (pb * 16 + r + ky * W + kx) * P3 + c0 + gk * 4);
-                if (!ok) av[pb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                av[pb] = *reinterpret_cast<const f32x4*>(wtap + pb * 16 * P3);
+                if (!((tapmask[pb] >> tap) & 1u)) av[pb] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
             for (int j = 0; j < TN3; ++j) {
