@@ -286,7 +286,7 @@ def main() -> None:
     ap.add_argument("--no-secondary", action="store_true", help="headline only: skip the fp16 B=128 and ResNet-50 fp8 B=256 lines")
     args = ap.parse_args()
     if args.batch is None:
-        args.batch = {"f32": 32, "f16": 128, "f8": 256}[args.dtype]
+        args.batch = {"f32": 32, "f16": 128, "f8": 256, "f32x6": 32}[args.dtype]
 
     from _pkg import load_package
     load_package()

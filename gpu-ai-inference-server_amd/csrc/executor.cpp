@@ -85,6 +85,7 @@ DeviceWeights::~DeviceWeights() {
     if (d_f8_aux) (void)hipFree(d_f8_aux);
     if (d_weights_wino) (void)hipFree(d_weights_wino);
     if (d_weights_x6) (void)hipFree(d_weights_x6);
+    if (d_weights_wino_x6) (void)hipFree(d_weights_wino_x6);
 }
 
 namespace {
@@ -299,6 +300,10 @@ void DeviceModel::BuildInstance(PlanInstance& pi, const std::vector<std::vector<
                         check(hipMalloc(&w_->d_weights_x6, size_t(xtot)), "hipMalloc(weights_x6)");
                         w_->device_bytes += size_t(xtot);
                     }
+                    if (utot > 0) {                     // the split Winograd U: 3 planes x 2 bytes against 4 bytes per element
+                        check(hipMalloc(&w_->d_weights_wino_x6, size_t(utot) * 6), "hipMalloc(weights_wino_x6)");
+                        w_->device_bytes += size_t(utot) * 6;
+                    }
                 }
             }
             if (w_->uploaded) WeightsArrived();
@@ -407,8 +412,11 @@ void DeviceModel::WeightsArrived() {
             check(LaunchSplitWeightsX6(w_->d_weights + xr.w_off, static_cast<char*>(w_->d_weights_x6) + xr.byte_off, xr.cout, xr.k, stream_), "split_weights_x6");
     if (w_->d_weights_wino) {
         check(hipSetDevice(device_), "hipSetDevice");
-        for (const auto& wr : w_->wino_regions)
+        for (const auto& wr : w_->wino_regions) {
             check(LaunchWinogradWeights(w_->d_weights + wr.w_off, w_->d_weights_wino + wr.u_off, wr.cout, wr.cin, stream_), "winograd_weights");
+            if (w_->d_weights_wino_x6)
+                check(LaunchWinogradWeightsX6(w_->d_weights + wr.w_off, static_cast<char*>(w_->d_weights_wino_x6) + wr.u_off * 6, wr.cout, wr.cin, stream_), "winograd_weights_x6");
+        }
         check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
     }
     if (!w_->d_weights16 && !w_->d_weights_frag) return;
@@ -1076,8 +1084,12 @@ ConvArgs DeviceModel::MakeConvArgs(const PlanInstance& pi, const Step& s) const 
     }
     if (s.algo == ConvAlgo::Wino3x3) {               // the Winograd kernel reads the transformed weights through `wfrag`
         a.wfrag = nullptr;
+        a.w16 = nullptr;
         for (const auto& wr : w_->wino_regions)
-            if (wr.w_off == s.w_off && w_->d_weights_wino) a.wfrag = w_->d_weights_wino + wr.u_off;
+            if (wr.w_off == s.w_off && w_->d_weights_wino) {
+                a.wfrag = w_->d_weights_wino + wr.u_off;
+                a.w16 = w_->d_weights_wino_x6 ? static_cast<const char*>(w_->d_weights_wino_x6) + wr.u_off * 6 : nullptr;
+            }
     }
     if (s.out.f8 || s.in.f8) {       // fp8 mode: e4m3 weights, per-channel epilogue multipliers, tensor scales
         const DeviceWeights& W = *w_;
@@ -1237,7 +1249,7 @@ static std::string kernel_label(const Step& s) {
             if (s.algo == ConvAlgo::Stem) return s.out.f8 ? "conv_stem_kernel<f16,e4m3 out>" : (s.out.f16 ? "conv_stem_kernel<f16>" : "conv_stem_kernel<f32>");
             if (s.algo == ConvAlgo::Ws1x1) return std::string(s.in.f16 ? "conv1x1_ws_f16_kernel<t" : "conv1x1_ws_f32_kernel<t") + std::to_string(s.tile) + ">";
             if (s.algo == ConvAlgo::Ws3x3) return "conv3x3_ws_f16_kernel<t" + std::to_string(s.tile) + ">";
-            if (s.algo == ConvAlgo::Wino3x3) return "conv3x3_wino_kernel<t" + std::to_string(s.tile) + ">";
+            if (s.algo == ConvAlgo::Wino3x3) return std::string(s.tile >= 8 ? "conv3x3_wino_x6_kernel<t" : "conv3x3_wino_kernel<t") + std::to_string(s.tile) + ">";
             if (s.algo == ConvAlgo::X6) return "conv1x1_x6_kernel<t" + std::to_string(s.tile) + ">";
             if (s.algo == ConvAlgo::Raster3x3)
                 return "conv3x3_raster_kernel<t" + std::to_string(s.tile) + (s.splitk > 1 ? ",splitk" + std::to_string(s.splitk) : std::string()) + ">";

@@ -49,6 +49,7 @@ struct DeviceWeights {
     std::vector<WinoRegion> wino_regions;
     // fp32 mode with IE_FP32_SPLIT=1: every eligible 1x1 conv's weights as three bf16 planes in MFMA-fragment order (kernels_x6.hip)
     void* d_weights_x6 = nullptr;
+    void* d_weights_wino_x6 = nullptr;   // and the Winograd U of every region of wino_regions as three bf16 planes (byte offset = 6 x its u_off)
     struct X6Region { int64_t w_off, byte_off; int cout, k; };
     std::vector<X6Region> x6_regions;
     bool fp32_split = false;

@@ -123,10 +123,11 @@ hipError_t LaunchConvStem(const ConvArgs& a, hipStream_t stream);
 hipError_t InitKernelsStem();
 // Winograd F(2x2, 3x3) conv (kernels_wino.hip): fp32, 3x3 / stride 1 / pad 1, 32 output channels, even H and W; a.wfrag = the transformed
 // weights U (16 x Cout x Cin floats, fragment-major) built by LaunchWinogradWeights.  tile: 0..3 = output tiles per workgroup.
-constexpr int kNumConvWinoTiles = 8;        // output tiles per workgroup: 4x7, 2x14, 4x8, 2x16; 0..3 four waves, 4..7 eight waves
+constexpr int kNumConvWinoTiles = 12;       // output tiles per workgroup: 4x7, 2x14, 4x8, 2x16; 0..3 four waves, 4..7 eight waves, 8..11 eight waves with bf16x6 products (need `w16` = LaunchWinogradWeightsX6's mirror)
 bool ConvWinoEligible(const ConvArgs& a, int tile);
 hipError_t LaunchConvWino3x3(const ConvArgs& a, int tile, hipStream_t stream);
 hipError_t LaunchWinogradWeights(const float* w, float* u, int Cout, int Cin, hipStream_t stream);
+hipError_t LaunchWinogradWeightsX6(const float* w, void* dst, int Cout, int Cin, hipStream_t stream);      // 3 x 16 x Cout x Cin bf16
 hipError_t InitKernelsWino();
 // fp32 1x1 conv on the bf16 matrix pipe with exactly split operands (kernels_x6.hip; opt-in, IE_FP32_SPLIT=1): `w16` points at the three
 // bf16 planes LaunchSplitWeightsX6 built from the conv's fp32 weights.  tile 0: 64 pixels per workgroup, 1: 32.

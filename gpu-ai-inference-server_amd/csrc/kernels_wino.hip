@@ -23,6 +23,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // U[xi = 4i + j][cout][cin] = (G g G^T)[i][j], G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], stored fragment-major for the MFMA B operand:
 // element ((xi * (Cin/8) + ch8) * 64 + lane) * 4 + e  =  U[xi][cout = lane & 31][cin = ch8*8 + (lane >> 5)*4 + e]
@@ -55,6 +56,52 @@ __global__ void winograd_weights_kernel(const float* __restrict__ w, float* __re
     }
 }
 
+// The same U as three bf16 planes (U = U0 + U1 + U2 exactly; kernels_x6.hip has the arithmetic) in the B-operand fragment order of
+// v_mfma_f32_32x32x16_bf16:  element ((((p * 16 + xi) * (Cin/16) + kb) * 64 + lane) * 8 + i  =  piece p of U[xi][lane & 31][kb*16 + (lane>>5)*8 + i]
+__global__ void winograd_weights_x6_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, const int Cout, const int Cin) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Cout * Cin) return;
+    const int co = idx / Cin, ci = idx - co * Cin;
+    float g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) g[a][b] = w[((co * 3 + a) * 3 + b) * Cin + ci];
+    float t[4][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        t[0][b] = g[0][b];
+        t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+        t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+        t[3][b] = g[2][b];
+    }
+    const int KB = Cin >> 4, kb = ci >> 4, lane = co + 32 * ((ci >> 3) & 1), e = ci & 7;
+    const int64_t plane = int64_t(16) * 32 * Cin;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float uu[4] = {t[i][0], 0.5f * (t[i][0] + t[i][1] + t[i][2]), 0.5f * (t[i][0] - t[i][1] + t[i][2]), t[i][2]};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x = uu[j];
+            const unsigned h0 = __builtin_bit_cast(unsigned, x) & 0xffff0000u;
+            const float r1 = x - __builtin_bit_cast(float, h0);
+            const unsigned h1 = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+            const unsigned h2 = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, h1));
+            const int64_t off = ((int64_t(4 * i + j) * KB + kb) * 64 + lane) * 8 + e;
+            dst[off] = static_cast<unsigned short>(h0 >> 16);
+            dst[plane + off] = static_cast<unsigned short>(h1 >> 16);
+            dst[2 * plane + off] = static_cast<unsigned short>(h2 >> 16);
+        }
+    }
+}
+
+hipError_t LaunchWinogradWeightsX6(const float* w, void* dst, int Cout, int Cin, hipStream_t stream) {
+    if (Cout != 32 || (Cin % 16) || Cin <= 0) return hipErrorInvalidValue;
+    const int total = Cout * Cin;
+    winograd_weights_x6_kernel<<<dim3((total + 255) / 256), dim3(256), 0, stream>>>(w, static_cast<unsigned short*>(dst), Cout, Cin);
+    return hipGetLastError();
+}
+
 hipError_t LaunchWinogradWeights(const float* w, float* u, int Cout, int Cin, hipStream_t stream) {
     if (Cout != 32 || (Cin % 16) || Cin <= 0) return hipErrorInvalidValue;
     const int total = Cout * Cin;
@@ -83,8 +130,12 @@ struct WinoGeom {
 // WAVES = 8 (tiles 4..7): two positions per wave instead of four -- half the MFMA chain per wave, four waves per SIMD instead of two
 // (124 VGPRs), at 10 v_pk per 8 MFMAs instead of 16 per 16.  Measured (wino_probe, 56x56x128 -> 32): one workgroup per CU 15.7 us
 // against 19.3, 3.5 per CU (batch 32) 50.0 us against 56.2; sixteen waves (one position each) gave nothing more (15.6 / 57.5).
-template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, WAVES == 8 ? 4 : 2))) void conv3x3_wino_kernel(const ConvArgs a, const WinoGeom g) {
+// X6 (tiles 8..11, eight waves, opt-in IE_FP32_SPLIT=1): the Winograd-domain products M_xi += V_xi . U_xi on the bf16 matrix pipe with both
+// operands split exactly into three bf16 pieces (kernels_x6.hip: six MFMAs per 32x32x16 block, fp32 accumulation, nothing above 2^-24 of
+// a product dropped).  V is transformed in fp32 as before and split in registers (VALU work that co-issues with the bf16 MFMAs); U comes
+// pre-split from LaunchWinogradWeightsX6 through `w16`.  One stage per 16-channel slice; a lane holds 8 channels.
+template <int WAVES, bool X6 = false>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, (WAVES == 8 && !X6) ? 4 : 2))) void conv3x3_wino_kernel(const ConvArgs a, const WinoGeom g) {
     constexpr int NT = 64 * WAVES, CS = 16, LP = CS + 4, MP = 32 + 4, PITW = 1024 / NT;
     constexpr int NJ = 16 / WAVES;                      // positions (columns j of row i) per wave
     constexpr unsigned OOB = 0x80000000u;
@@ -157,6 +208,117 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, W
     const int ltr = r / g.TC, ltc = r - ltr * g.TC;
     const int col0 = NJ == 4 ? 0 : jh;
     const int dA = ((2 * ltr + ra) * WC + 2 * ltc + col0) * LP + hh * 4, dB = ((2 * ltr + rb) * WC + 2 * ltc + col0) * LP + hh * 4;
+    f32x16 acc[NJ];
+#pragma unroll
+    for (int xl = 0; xl < NJ; ++xl)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[xl][e] = 0.f;
+    if constexpr (X6) {
+        static_assert(NJ == 2, "the split variant is written for eight waves");
+        const __amdgpu_buffer_rsrc_t rs_ux = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w16), 0, 3 * 16 * 32 * Cin * 2, 0x00020000);
+        const int KB = Cin >> 4;
+        const int plane_b = 16 * 32 * Cin * 2;          // bytes per plane
+        u32x4 ux0[NJ][3], ux1[NJ][3];                   // U fragments: even / odd slices
+        auto issue_ux = [&](u32x4 (&ux)[NJ][3], int sl) {
+            const int kb = sl < nslices ? sl : nslices - 1;
+#pragma unroll
+            for (int xl = 0; xl < NJ; ++xl)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) ux[xl][p] = __builtin_amdgcn_raw_buffer_load_b128(rs_ux, unsigned(lane) * 16u, p * plane_b + ((NJ * wave + xl) * KB + kb) * 1024, 0);
+        };
+        // window rows ra / rb, columns jh .. jh+2, this lane's EIGHT channels (two quads) of the slice
+        const float* const qdA[2] = {sWin + dA + hh * 4, sWin + win_floats + dA + hh * 4};      // dA carries hh * 4: + hh * 4 more = hh * 8
+        const float* const qdB[2] = {sWin + dB + hh * 4, sWin + win_floats + dB + hh * 4};
+        f32x4 xra[3][2], xrb[3][2];
+        auto read_dx = [&](int buf) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    xra[c][q] = *reinterpret_cast<const f32x4*>(qdA[buf] + c * LP + q * 4);
+                    xrb[c][q] = *reinterpret_cast<const f32x4*>(qdB[buf] + c * LP + q * 4);
+                }
+        };
+        const float ka0 = jh == 0 ? 1.f : -1.f, ka1 = jh == 0 ? 0.f : 1.f, ka2 = jh == 0 ? -1.f : 0.f;
+        const float kb0 = jh == 0 ? 0.f : 1.f, kb1 = jh == 0 ? 1.f : 0.f, kb2 = jh == 0 ? 1.f : -1.f;
+        u32x4 axA[NJ][3], axB[NJ][3];                   // split A fragments: even / odd slices
+        auto make_ax = [&](u32x4 (&ax)[NJ][3]) {
+            f32x4 v[NJ][2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                f32x4 m[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) m[c] = xra[c][q] + sg * xrb[c][q];
+                // branch-free (one scheduling region with the MFMAs): columns jh .. jh+2 with wave-uniform coefficients
+                //   jh = 0: V0 = m0 - m2, V1 = m1 + m2;   jh = 1 (m = columns 1..3): V2 = m1 - m0, V3 = m0 - m2
+                v[0][q] = ka0 * m[0] + ka1 * m[1] + ka2 * m[2];
+                v[1][q] = kb0 * m[0] + kb1 * m[1] + kb2 * m[2];
+            }
+#pragma unroll
+            for (int xl = 0; xl < NJ; ++xl) {
+                unsigned h0[8], h1[8], h2[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float x = v[xl][e >> 2][e & 3];
+                    h0[e] = __builtin_bit_cast(unsigned, x);
+                    const float r1 = x - __builtin_bit_cast(float, h0[e] & 0xffff0000u);
+                    h1[e] = __builtin_bit_cast(unsigned, r1);
+                    h2[e] = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, h1[e] & 0xffff0000u));
+                }
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    ax[xl][0][d] = __builtin_amdgcn_perm(h0[2 * d + 1], h0[2 * d], 0x07060302u);
+                    ax[xl][1][d] = __builtin_amdgcn_perm(h1[2 * d + 1], h1[2 * d], 0x07060302u);
+                    ax[xl][2][d] = __builtin_amdgcn_perm(h2[2 * d + 1], h2[2 * d], 0x07060302u);
+                }
+            }
+        };
+        auto mfmas_x = [&](const u32x4 (&ax)[NJ][3], const u32x4 (&ux)[NJ][3]) {
+#pragma unroll
+            for (int xl = 0; xl < NJ; ++xl) {
+                const bf16x8 a0 = __builtin_bit_cast(bf16x8, ax[xl][0]), a1 = __builtin_bit_cast(bf16x8, ax[xl][1]), a2 = __builtin_bit_cast(bf16x8, ax[xl][2]);
+                const bf16x8 b0 = __builtin_bit_cast(bf16x8, ux[xl][0]), b1 = __builtin_bit_cast(bf16x8, ux[xl][1]), b2 = __builtin_bit_cast(bf16x8, ux[xl][2]);
+                acc[xl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[xl], 0, 0, 0);      // smallest terms first
+                acc[xl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[xl], 0, 0, 0);
+                acc[xl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[xl], 0, 0, 0);
+                acc[xl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[xl], 0, 0, 0);
+                acc[xl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[xl], 0, 0, 0);
+                acc[xl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[xl], 0, 0, 0);
+            }
+        };
+        // ---- prologue: windows 0 and 1 in LDS, slice 0 transformed and split ----
+        issue_window(pvA, 0);
+        issue_window(pvB, 1);
+        issue_ux(ux0, 0);
+        commit_window(pvA, 0);
+        issue_window(pvA, 2);
+        __syncthreads();
+        read_dx(0);
+        make_ax(axA);
+        commit_window(pvB, 1);
+        issue_window(pvB, 3);
+        __syncthreads();
+        // slice s: MFMAs on the fragments made one trip earlier, while slice s+1 is read, transformed and split
+        auto xslice = [&](auto parity, int sl, u32x4 (&a_cur)[NJ][3], u32x4 (&a_nxt)[NJ][3], u32x4 (&u_cur)[NJ][3], u32x4 (&u_nxt)[NJ][3], f32x4 (&pv_c)[PITW]) {
+            constexpr int P = decltype(parity)::value;     // window buffer that held slice s
+            read_dx(P ^ 1);
+            issue_ux(u_nxt, sl + 1);
+            mfmas_x(a_cur, u_cur);
+            make_ax(a_nxt);
+#pragma unroll
+            for (int i = 0; i < 6 * NJ; ++i) {              // the split of slice s+1 threaded between the MFMAs of slice s (a wave issues in order)
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);
+            }
+            commit_window(pv_c, P);                         // window of slice s+2 (last reader of this buffer: the read of slice s, one trip back)
+            issue_window(pv_c, sl + 4);
+            __syncthreads();
+        };
+        for (int sl = 0; sl < nslices; sl += 2) {
+            xslice(std::integral_constant<int, 0>{}, sl, axA, axB, ux0, ux1, pvA);
+            xslice(std::integral_constant<int, 1>{}, sl + 1, axB, axA, ux1, ux0, pvB);
+        }
+    } else {
     const int c8n = Cin >> 3;
     u32x4 ub0[NJ], ub1[NJ];
     auto issue_u = [&](u32x4 (&ub)[NJ], int h) {
@@ -192,11 +354,6 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, W
             af[1] = m[0] - m[2];
         }
     };
-    f32x16 acc[NJ];
-#pragma unroll
-    for (int xl = 0; xl < NJ; ++xl)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[xl][e] = 0.f;
     auto mfmas = [&](const u32x4 (&ub)[NJ]) {
         f32x4 ac[NJ];
 #pragma unroll
@@ -236,6 +393,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, W
     for (int s = 0; s < nslices; s += 2) {
         slice(std::integral_constant<int, 0>{}, s, pvB);
         slice(std::integral_constant<int, 1>{}, s + 1, pvA);
+    }
     }
     __syncthreads();                                    // every wave is done with the windows: the storage becomes sM
 
@@ -296,7 +454,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, W
 }
 
 struct WinoTile { int tr, tc; };
-constexpr WinoTile kWinoTiles[kNumConvWinoTiles] = {{4, 7}, {2, 14}, {4, 8}, {2, 16}, {4, 7}, {2, 14}, {4, 8}, {2, 16}};      // 4..7: eight waves
+constexpr WinoTile kWinoTiles[kNumConvWinoTiles] = {{4, 7}, {2, 14}, {4, 8}, {2, 16}, {4, 7}, {2, 14}, {4, 8}, {2, 16}, {4, 7}, {2, 14}, {4, 8}, {2, 16}};      // 4..7: eight waves; 8..11: eight waves, bf16x6 products
 
 static size_t wino_lds_bytes(int tr, int tc) {
     const size_t npx = size_t(2 * tr + 2) * (2 * tc + 2);
@@ -318,6 +476,7 @@ bool ConvWinoEligible(const ConvArgs& a, int tile) {
     if (M * a.in.sw * 4 >= (int64_t(1) << 31) || M * a.out.sw * 4 >= (int64_t(1) << 31)) return false;
     const WinoTile t = kWinoTiles[tile];
     if ((2 * t.tr + 2) * (2 * t.tc + 2) * 4 > 4 * 256) return false;      // window prefetch slots
+    if (tile >= 8 && (a.w16 == nullptr || (reinterpret_cast<uintptr_t>(a.w16) & 15))) return false;      // the split U mirror (IE_FP32_SPLIT=1)
     return t.tr * t.tc <= 32 && wino_lds_bytes(t.tr, t.tc) <= size_t(64) * 1024;
 }
 
@@ -333,7 +492,8 @@ hipError_t LaunchConvWino3x3(const ConvArgs& a_in, int tile, hipStream_t stream)
     g.brx = (g.TW + g.TC - 1) / g.TC;
     const int64_t blocks = int64_t(a.in.n) * g.bry * g.brx;
     if (blocks >= (int64_t(1) << 31)) return hipErrorInvalidValue;
-    if (tile >= 4) conv3x3_wino_kernel<8><<<dim3(unsigned(blocks)), dim3(512), wino_lds_bytes(t.tr, t.tc), stream>>>(a, g);
+    if (tile >= 8) conv3x3_wino_kernel<8, true><<<dim3(unsigned(blocks)), dim3(512), wino_lds_bytes(t.tr, t.tc), stream>>>(a, g);
+    else if (tile >= 4) conv3x3_wino_kernel<8><<<dim3(unsigned(blocks)), dim3(512), wino_lds_bytes(t.tr, t.tc), stream>>>(a, g);
     else conv3x3_wino_kernel<4><<<dim3(unsigned(blocks)), dim3(256), wino_lds_bytes(t.tr, t.tc), stream>>>(a, g);
     return hipGetLastError();
 }
@@ -341,7 +501,8 @@ hipError_t LaunchConvWino3x3(const ConvArgs& a_in, int tile, hipStream_t stream)
 hipError_t InitKernelsWino() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)) != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
 }
 
 }  // namespace ie

@@ -1045,7 +1045,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                         if (wino_ok) {
                             s.algo = ConvAlgo::Wino3x3;
                             s.tile = 0;
-                            if (const char* ft = std::getenv("IE_FORCE_TILE")) { int t = std::atoi(ft); if (t >= 0 && t < 8) s.tile = t; }
+                            if (const char* ft = std::getenv("IE_FORCE_TILE")) { int t = std::atoi(ft); if (t >= 0 && t < 12) s.tile = t; }
                         } else if (s.algo == ConvAlgo::Naive)
                             s.algo = (vec_ok || vec16_ok) ? ConvAlgo::IgemmVec : (K <= 2048 && !in16 ? ConvAlgo::IgemmScalar : ConvAlgo::Naive);
                     }

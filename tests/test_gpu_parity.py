@@ -1610,7 +1610,7 @@ def test_bf16x6_1x1_kernel(tmp_path, tile, batch, image, blocks):
     assert e < RTOL and e < 3 * e0 + 1e-7 and rel_err(y, y0) < 2e-5
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
 @pytest.mark.parametrize("batch,image,blocks", [(3, 64, (2, 2)), (2, 112, (3,)), (5, 48, (2, 1))])
 def test_winograd_3x3_kernel(tmp_path, tile, batch, image, blocks):
     """conv3x3_wino_kernel (Winograd F(2x2, 3x3): 16 multiplies per 2x2 output tile instead of 36) forced onto every eligible growth
@@ -1631,7 +1631,10 @@ def test_winograd_3x3_kernel(tmp_path, tile, batch, image, blocks):
             m.Destroy()
         np.testing.assert_array_equal(y, y2)
         return plan, y
-    plan, y = _run_with_env(dict(IE_FORCE_ALGO="wino", IE_FORCE_TILE=str(tile)), go)
+    env = dict(IE_FORCE_ALGO="wino", IE_FORCE_TILE=str(tile))
+    if tile >= 8:                                   # tiles 8-11: the Winograd-domain products as bf16x6 (opt-in mirror)
+        env["IE_FP32_SPLIT"] = "1"
+    plan, y = _run_with_env(env, go)
     nw = [s for s in plan["steps"] if s.get("algo") == "wino3x3"]
     assert len(nw) == sum(blocks) and all(s["out"]["c"] == 32 for s in nw)
     _, y0 = _run_with_env(dict(IE_AUTOTUNE="0"), go)
