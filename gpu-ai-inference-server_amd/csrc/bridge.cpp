@@ -257,7 +257,7 @@ struct ModelObj {
     void BroadcastWeights();                      // RCCL: primary's packed blob -> every other weight owner
     void Account(ie::DeviceModel& d, const ie::PlanInstance& pi);
     using Segs = std::pair<std::vector<std::vector<ie::DeviceModel::InSeg>>, std::vector<std::vector<ie::DeviceModel::OutSeg>>>;
-    const ie::PlanInstance* RunOnLanes(const std::vector<std::vector<int64_t>>& shapes, int64_t rows, bool allow_shard, const Segs& segs, bool* sharded);
+    std::vector<ie::IoDesc> RunOnLanes(const std::vector<std::vector<int64_t>>& shapes, int64_t rows, bool allow_shard, const Segs& segs, bool* sharded);
 };
 
 #define NCCL_OK(call)                                                                                             \
@@ -315,7 +315,10 @@ void ModelObj::BroadcastWeights() {
     }
     auto t2 = std::chrono::steady_clock::now();
     for (auto c : comms) if (c) (void)ncclCommDestroy(c);
-    for (size_t i = 1; i < owners.size(); ++i) owners[i]->WeightsArrived();
+    // receivers rebuild their derived mirrors; in fp8 mode they adopt the primary's calibrated activation scales (same weights, same
+    // hardware: re-running the calibration pass on every receiver would be 8x redundant work at load)
+    const std::vector<float> scales = owners[0]->f8_act_scales();
+    for (size_t i = 1; i < owners.size(); ++i) owners[i]->WeightsArrived(scales.empty() ? nullptr : &scales);
     (void)hipSetDevice(device_id);
     rccl.used = true;
     rccl.ranks = int(devs.size());
@@ -802,9 +805,10 @@ void ModelObj::Account(ie::DeviceModel& d, const ie::PlanInstance& pi) {
 
 // Run one device batch described by gather/scatter segments over `rows` rows (rows == 0: the shapes are used as they are and the
 // batch cannot be cut).  One lane, or -- allow_shard, num_shards > 1 and at least one row per replica -- contiguous row slices on
-// all shard lanes at once (slice k on worker thread k-1, slice 0 on the calling thread).  Returns the plan instance that describes
-// the outputs (the caller holds `life` shared, so the pointer stays valid).
-const ie::PlanInstance* ModelObj::RunOnLanes(const std::vector<std::vector<int64_t>>& shapes, int64_t rows, bool allow_shard, const Segs& segs,
+// all shard lanes at once (slice k on worker thread k-1, slice 0 on the calling thread).  Returns a COPY of the output descriptors
+// of the plan that ran, taken while the lane is still held: once a lane is released any other request may take it and `Prepare` a
+// new shape there, which can evict (free) this plan instance from the lane's bounded cache.
+std::vector<ie::IoDesc> ModelObj::RunOnLanes(const std::vector<std::vector<int64_t>>& shapes, int64_t rows, bool allow_shard, const Segs& segs,
                                              bool* sharded) {
     const int S = num_shards;
     *sharded = false;
@@ -816,8 +820,9 @@ const ie::PlanInstance* ModelObj::RunOnLanes(const std::vector<std::vector<int64
             ie::PlanInstance& pi = D.Prepare(shapes, false);
             D.InferHostSegments(pi, segs.first, segs.second);
             Account(D, pi);
+            std::vector<ie::IoDesc> outs = pi.plan.outputs;
             pool.Release(k, 1);
-            return &pi;
+            return outs;
         } catch (...) {
             pool.Release(k, 1);
             throw;
@@ -871,6 +876,8 @@ const ie::PlanInstance* ModelObj::RunOnLanes(const std::vector<std::vector<int64
     for (int k = 1; k < S; ++k) workers.Submit(size_t(k - 1), [&run_slice, k] { run_slice(k); });
     run_slice(0);
     workers.Wait();
+    std::vector<ie::IoDesc> outs0;
+    if (pis[0]) outs0 = pis[0]->plan.outputs;
     pool.Release(0, S);
     for (auto& e : errs) if (!e.empty()) throw std::runtime_error(e);
     // the slices wrote only the bytes they produced: zero-fill whatever a caller buffer has beyond its result
@@ -880,7 +887,7 @@ const ie::PlanInstance* ModelObj::RunOnLanes(const std::vector<std::vector<int64
             if (sg.cap > nb) std::memset(static_cast<char*>(sg.host) + nb, 0, sg.cap - nb);
         }
     *sharded = true;
-    return pis[0];
+    return outs0;
 }
 
 void ModelObj::Execute(std::vector<Pending*>& batch) {
@@ -923,8 +930,8 @@ void ModelObj::Execute(std::vector<Pending*>& batch) {
                 }
             }
             if (same_rows && num_shards > 1 && rows >= num_shards) {
-                const ie::PlanInstance* pi = RunOnLanes(r.shapes, rows, true, segs, &sharded);
-                write_out_dims(r.outputs, r.num_outputs, pi->plan.outputs, rows);
+                const std::vector<ie::IoDesc> outs = RunOnLanes(r.shapes, rows, true, segs, &sharded);
+                write_out_dims(r.outputs, r.num_outputs, outs, rows);
                 if (sharded) shard_calls.fetch_add(1);
                 r.ok = true;
                 return;
@@ -997,12 +1004,12 @@ void ModelObj::Execute(std::vector<Pending*>& batch) {
         }
         // rows of the bucket beyond `total` stay whatever the input buffer held: they are padding whose results nobody reads
         bool sharded = false;
-        const ie::PlanInstance* pi = RunOnLanes(shapes, bucket, out_known, segs, &sharded);
+        const std::vector<ie::IoDesc> outs = RunOnLanes(shapes, bucket, out_known, segs, &sharded);
         device_batches.fetch_add(1);
         coalesced_requests.fetch_add(int64_t(batch.size()));
         if (sharded) shard_calls.fetch_add(1);
         for (auto* r : batch) {
-            write_out_dims(r->outputs, r->num_outputs, pi->plan.outputs, r->rows);
+            write_out_dims(r->outputs, r->num_outputs, outs, r->rows);
             r->ok = true;
         }
     } catch (const std::exception& e) {
@@ -1104,6 +1111,17 @@ std::string describe_runtime(ModelObj& M, bool json, bool checksums = false) {
             (void)hipSetDevice(M.lanes[i]->device());
             if (hipMemcpy(host.data(), M.lanes[i]->weights(), host.size(), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); host.clear(); }
             o << (i ? "," : "") << "\"" << std::hex << fnv1a64(host.data(), host.size()) << std::dec << "\"";
+        }
+        // and of everything derived from it per lane (half / fragment-major / Winograd U / bf16x6 / e4m3 + scales)
+        o << "],\"mirror_checksums\":[";
+        for (size_t i = 0; i < M.lanes.size(); ++i) {
+            o << (i ? "," : "") << "{";
+            bool first = true;
+            for (const auto& kv : M.lanes[i]->MirrorChecksums()) {
+                o << (first ? "" : ",") << "\"" << kv.first << "\":\"" << std::hex << kv.second << std::dec << "\"";
+                first = false;
+            }
+            o << "}";
         }
         o << "]";
     }
@@ -1386,11 +1404,20 @@ bool EngineGetWeightBlob(ModelHandle handle, void** d_ptr, size_t* bytes, ErrorM
 bool EngineWeightsUpdated(ModelHandle handle, ErrorMessage* error) {
     if (!handle) { set_error(error, "Invalid parameters"); return false; }
     try {
+        // The primary's fp32 blob was rewritten in place.  Every lane may be running a forward on the derived mirrors (extra
+        // instance_count lanes and same-device shards share them), so ALL lanes are held for the update; replicas that own a blob of
+        // their own (other devices, IE_SHARD_PRIVATE_WEIGHTS) get the new weights through the same broadcast as at load.
         ModelObj& M = *handle->model;
-        Lane0 L0(M);
-        if (!L0.dev()) { set_error(error, "Model not loaded"); return false; }
-        L0.dev()->Synchronize();
-        L0.dev()->WeightsArrived();
+        std::shared_lock<std::shared_mutex> g(M.life);
+        if (!M.loaded.load() || M.lanes.empty()) { set_error(error, "Model not loaded"); return false; }
+        const int n = int(M.lanes.size());
+        M.pool.AcquireRange(n);
+        try {
+            for (auto& l : M.lanes) l->Synchronize();
+            M.lanes[0]->WeightsArrived();
+            M.BroadcastWeights();
+        } catch (...) { M.pool.Release(0, n); throw; }
+        M.pool.Release(0, n);
         return true;
     } catch (const std::exception& e) { set_error(error, e.what()); return false; }
     catch (...) { set_error(error, "unknown error"); return false; }

@@ -245,6 +245,7 @@ void DeviceModel::BuildInstance(PlanInstance& pi, const std::vector<std::vector<
                         aux += 2 * ((st.out.c + 3) / 4 * 4);
                     }
                     check(hipMalloc(reinterpret_cast<void**>(&w_->d_f8_aux), size_t(std::max<int64_t>(aux, 4)) * sizeof(float)), "hipMalloc(f8 aux)");
+                    w_->f8_aux_floats = size_t(aux);
                     w_->device_bytes += size_t(aux) * sizeof(float);
                     w_->act_scale.assign(pi.plan.steps.size(), 0.f);
                 }
@@ -278,6 +279,7 @@ void DeviceModel::BuildInstance(PlanInstance& pi, const std::vector<std::vector<
                 }
                 if (utot > 0) {
                     check(hipMalloc(reinterpret_cast<void**>(&w_->d_weights_wino), size_t(utot) * sizeof(float)), "hipMalloc(weights_wino)");
+                    w_->wino_floats = size_t(utot);
                     w_->device_bytes += size_t(utot) * sizeof(float);
                 }
                 // bf16x6 mirrors (opt-in): the 1x1 convs the split kernel can run, whatever step they are part of in this plan instance
@@ -298,6 +300,7 @@ void DeviceModel::BuildInstance(PlanInstance& pi, const std::vector<std::vector<
                     }
                     if (xtot > 0) {
                         check(hipMalloc(&w_->d_weights_x6, size_t(xtot)), "hipMalloc(weights_x6)");
+                        w_->x6_bytes = size_t(xtot);
                         w_->device_bytes += size_t(xtot);
                     }
                     if (utot > 0) {                     // the split Winograd U: 3 planes x 2 bytes against 4 bytes per element
@@ -389,7 +392,10 @@ PlanInstance& DeviceModel::Prepare(const std::vector<std::vector<int64_t>>& shap
         BuildInstance(*pi, shapes);
         check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
         if (autotune_) Autotune(*pi, pi->plan.steps.size(), allow_tune || tune_on_demand_);
-        if (use_graph_) {
+        // fp8 mode bakes the activation scales into the launches: nothing is captured before they exist (a replica that owns a
+        // never-uploaded blob is built before the weight broadcast); RefreshGraphs captures on first use
+        if (use_graph_ && !(precision_ == Precision::F8 && !w_->f8_ready)) {
+            pi->captured_gen = w_->f8_gen.load();
             Capture(*pi, 0, pi->plan.steps.size(), &pi->graph_exec);
             pi->graph_ready = true;
         }
@@ -405,7 +411,8 @@ PlanInstance& DeviceModel::Prepare(const std::vector<std::vector<int64_t>>& shap
 }
 
 // Rebuilds what is derived from the fp32 weight blob: the half mirror (fp16 mode) or the fragment-major conv weights (fp32 mode).
-void DeviceModel::WeightsArrived() {
+void DeviceModel::WeightsArrived(const std::vector<float>* adopt_act_scales) {
+    check(hipSetDevice(device_), "hipSetDevice");
     w_->uploaded = true;
     if (w_->d_weights_x6)
         for (const auto& xr : w_->x6_regions)
@@ -427,7 +434,41 @@ void DeviceModel::WeightsArrived() {
         for (const DeviceWeights::FragRegion& fr : w_->frag_regions)
             check(LaunchPermuteWeightsFrag(w_->d_weights + fr.w_off, w_->d_weights_frag + fr.w_off, fr.cout, fr.kk, fr.cin, stream_), "permute_weights_frag");
     check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
-    if (precision_ == Precision::F8) PrepareF8();
+    if (precision_ == Precision::F8) PrepareF8(adopt_act_scales);
+}
+
+std::vector<std::pair<std::string, uint64_t>> DeviceModel::MirrorChecksums() {
+    check(hipSetDevice(device_), "hipSetDevice");
+    check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+    const DeviceWeights& W = *w_;
+    std::vector<std::pair<std::string, uint64_t>> out;
+    std::vector<char> host;
+    auto fnv = [](uint64_t h, const char* p, size_t n) { for (size_t i = 0; i < n; ++i) { h ^= uint8_t(p[i]); h *= 0x100000001B3ull; } return h; };
+    auto pull = [&](const void* dev, size_t bytes) {
+        host.resize(bytes);
+        if (bytes) check(hipMemcpy(host.data(), dev, bytes, hipMemcpyDeviceToHost), "hipMemcpy(mirror)");
+    };
+    constexpr uint64_t kBasis = 0xCBF29CE484222325ull;
+    if (W.d_weights16) { pull(W.d_weights16, W.weight_floats * 2); out.push_back({"half", fnv(kBasis, host.data(), host.size())}); }
+    if (W.d_weights_frag) {        // only the conv regions of the fragment-major blob are ever written
+        uint64_t h = kBasis;
+        for (const auto& fr : W.frag_regions) {
+            pull(W.d_weights_frag + fr.w_off, size_t(fr.cout) * size_t(fr.kk) * size_t(fr.cin) * sizeof(float));
+            h = fnv(h, host.data(), host.size());
+        }
+        out.push_back({"fragment_major", h});
+    }
+    if (W.d_weights_wino) { pull(W.d_weights_wino, W.wino_floats * sizeof(float)); out.push_back({"winograd_u", fnv(kBasis, host.data(), host.size())}); }
+    if (W.d_weights_x6) { pull(W.d_weights_x6, W.x6_bytes); out.push_back({"bf16x6", fnv(kBasis, host.data(), host.size())}); }
+    if (W.d_weights8) {
+        uint64_t h = kBasis;
+        for (const auto& fc : W.f8_convs) { pull(static_cast<const char*>(W.d_weights8) + fc.w_off, size_t(fc.cout) * size_t(fc.k)); h = fnv(h, host.data(), host.size()); }
+        out.push_back({"e4m3", h});
+        pull(W.d_f8_aux, W.f8_aux_floats * sizeof(float));
+        out.push_back({"e4m3_scales", fnv(kBasis, host.data(), host.size())});
+        out.push_back({"act_scales", fnv(kBasis, reinterpret_cast<const char*>(W.act_scale.data()), W.act_scale.size() * sizeof(float))});
+    }
+    return out;
 }
 
 namespace {
@@ -476,14 +517,17 @@ std::vector<float> synthetic_images(int64_t b, int64_t c, int64_t h, int64_t w, 
 //      draw saturate only beyond twice the calibrated range; e4m3 precision is relative, the headroom costs no mantissa bits);
 //      max pools keep their input's scale (their output IS one of their inputs);
 //   3. epilogue multipliers escale[o] = (input tensor scale) x (weight row scale).
-void DeviceModel::PrepareF8() {
+void DeviceModel::PrepareF8(const std::vector<float>* adopt) {
     DeviceWeights& W = *w_;
     if (W.f8_ready || !W.uploaded) return;
+    if (adopt && adopt->size() != W.act_scale.size()) adopt = nullptr;
     check(hipSetDevice(device_), "hipSetDevice");
     for (const auto& fc : W.f8_convs)
         check(LaunchQuantizeRowsE4m3(W.d_weights + fc.w_off, static_cast<char*>(W.d_weights8) + fc.w_off, W.d_f8_aux + fc.aux_off, fc.cout, fc.k, stream_),
               "quantize_rows_e4m3");
-    // ---- calibration pass in fp16 ----
+    // ---- calibration pass in fp16 (skipped when the scales of the weight owner that already calibrated are adopted) ----
+    if (adopt) W.act_scale = *adopt;
+    else {
     int64_t nc = 8;
     if (const char* e = std::getenv("IE_F8_CALIB_BATCH")) nc = std::max(1, std::min(64, std::atoi(e)));
     float margin = 2.0f;
@@ -529,12 +573,14 @@ void DeviceModel::PrepareF8() {
     }
     (void)hipFree(d_amax);
     FreeInstance(cal);
+    }
     for (const auto& fc : W.f8_convs) {
         if (fc.in_src < 0) throw std::runtime_error("fp8 precision: a conv reads a tensor whose producer is unknown");
         const int64_t half = (fc.cout + 3) / 4 * 4;
         check(LaunchScaleVector(W.d_f8_aux + fc.aux_off, W.d_f8_aux + fc.aux_off + half, W.act_scale[size_t(fc.in_src)], fc.cout, stream_), "scale_vector");
     }
     check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+    W.f8_gen.fetch_add(1);
     W.f8_ready = true;
 }
 
@@ -666,7 +712,7 @@ void DeviceModel::EnsurePipeline(PlanInstance& pi, bool allow_tune) {
                     d.algo = s0.algo; d.tile = s0.tile; d.splitk = s0.splitk;
                 }
         }
-        if (use_graph_) {
+        if (use_graph_ && !(precision_ == Precision::F8 && !w_->f8_ready) && pi.graph_ready) {
             for (auto& ch : pi.chunks) { Capture(*ch, 0, head, &ch->graph_exec); ch->graph_ready = true; }
             Capture(pi, head, pi.plan.steps.size(), &pi.tail_exec);
         }
@@ -1275,8 +1321,36 @@ void DeviceModel::RunSteps(PlanInstance& pi, size_t first, size_t last, std::vec
     }
 }
 
+// Graphs hold the fp8 activation scales as by-value kernel arguments: an instance captured before the scales existed (deferred) or
+// under scales that have since been recalibrated (EngineWeightsUpdated, the weight broadcast) is captured again here, on the lane
+// that owns it, before its next launch.
+void DeviceModel::RefreshGraphs(PlanInstance& pi) {
+    if (!use_graph_) return;
+    if (precision_ == Precision::F8 && !w_->f8_ready) throw std::runtime_error("fp8 precision: scales are not calibrated yet");
+    const uint64_t gen = w_->f8_gen.load();
+    if (pi.graph_ready && pi.captured_gen == gen) return;
+    check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+    auto drop = [](hipGraphExec_t& g) { if (g) (void)hipGraphExecDestroy(g); g = nullptr; };
+    drop(pi.graph_exec);
+    pi.graph_ready = false;
+    Capture(pi, 0, pi.plan.steps.size(), &pi.graph_exec);
+    pi.graph_ready = true;
+    if (!pi.chunks.empty() && pi.head_steps > 0) {
+        for (auto& ch : pi.chunks) {
+            drop(ch->graph_exec);
+            ch->graph_ready = false;
+            Capture(*ch, 0, size_t(pi.head_steps), &ch->graph_exec);
+            ch->graph_ready = true;
+        }
+        drop(pi.tail_exec);
+        Capture(pi, size_t(pi.head_steps), pi.plan.steps.size(), &pi.tail_exec);
+    }
+    pi.captured_gen = gen;
+}
+
 void DeviceModel::Enqueue(PlanInstance& pi) {
     check(hipSetDevice(device_), "hipSetDevice");
+    RefreshGraphs(pi);
     if (pi.graph_ready) check(hipGraphLaunch(pi.graph_exec, stream_), "hipGraphLaunch");
     else RunSteps(pi, 0, pi.plan.steps.size(), nullptr);
 }
@@ -1350,6 +1424,7 @@ void DeviceModel::InferHost(PlanInstance& pi, const std::vector<const void*>& in
 void DeviceModel::InferHostSegments(PlanInstance& pi, const std::vector<std::vector<InSeg>>& in, const std::vector<std::vector<OutSeg>>& out) {
     check(hipSetDevice(device_), "hipSetDevice");
     EnsurePipeline(pi, false);
+    RefreshGraphs(pi);
     const int C = pi.chunks.empty() ? 1 : int(pi.chunks.size());
     struct Job { int chunk; char* dst; const char* src; size_t copy, zero; };      // copy `copy` bytes src -> dst, then zero `zero` bytes behind them
     std::vector<Job> jobs;

@@ -16,6 +16,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "kernels.h"
@@ -43,6 +44,7 @@ struct DeviceWeights {
     std::vector<F8Conv> f8_convs;
     std::vector<float> act_scale;
     bool f8_ready = false;
+    std::atomic<uint64_t> f8_gen{0};   // bumped whenever act_scale / escale change: graphs captured under an older value are stale (scales are by-value kernel arguments)
     // fp32 mode: Winograd-transformed weights U (16 x Cout x Cin floats per eligible 3x3 conv, fragment-major), own offsets
     float* d_weights_wino = nullptr;
     struct WinoRegion { int64_t w_off, u_off; int cout, cin; };
@@ -56,6 +58,7 @@ struct DeviceWeights {
     struct FragRegion { int64_t w_off; int cout, kk, cin; };
     std::vector<FragRegion> frag_regions;
     size_t weight_floats = 0;
+    size_t wino_floats = 0, x6_bytes = 0, f8_aux_floats = 0;   // sizes of the derived allocations (checksums / observability)
     bool uploaded = false;             // the fp32 blob holds the model's weights (false until the upload or the broadcast happened)
     std::atomic<size_t> device_bytes{0};
     // kernel choices found by the search, shared by every lane of the device: conv signature -> (encoded tile, split-K)
@@ -76,6 +79,7 @@ struct PlanInstance {
     int* counters = nullptr;           // split-K arrival counters (zero between launches)
     hipGraphExec_t graph_exec = nullptr;   // the whole forward (device-resident replay); for a chunk instance: its head steps
     bool graph_ready = false;
+    uint64_t captured_gen = 0;         // DeviceWeights::f8_gen the graphs of this instance were captured under
     std::vector<void*> u8_stage;       // per graph input: device staging for UINT8 payloads (allocated on first use)
     // ---- pipelined host path (ModelInfer): the batch is cut into `chunks.size()` image ranges; the first `head_steps` steps run
     // per range as soon as that range's H2D has landed (every step is batch-parallel, a range is a pointer offset), the rest runs
@@ -136,7 +140,13 @@ public:
     Precision precision() const { return precision_; }
     bool fp32_split() const { return fp32_split_; }           // fp32 mode with the bf16x6 kernels in the search
     // The fp32 blob was (re)written in place (RCCL broadcast, EngineWeightsUpdated): rebuild the half / fragment-major mirrors.
-    void WeightsArrived();
+    // adopt_act_scales (fp8 mode): take these per-step activation scales (the weight owner that calibrated them) instead of running
+    // the calibration pass again -- receivers of the weight broadcast hold the same weights on the same hardware.
+    void WeightsArrived(const std::vector<float>* adopt_act_scales = nullptr);
+    std::vector<float> f8_act_scales() const { return w_->act_scale; }
+    // FNV-1a of every mirror derived from the fp32 blob as it sits in HBM (half / fragment-major / Winograd U / bf16x6 / e4m3 + scales):
+    // a replica filled by the weight broadcast must end up with the primary's derived data too.  Call with the lane held.
+    std::vector<std::pair<std::string, uint64_t>> MirrorChecksums();
     size_t weight_bytes() const { return w_->weight_floats * sizeof(float); }
     size_t device_bytes() const { return device_bytes_ + w_->device_bytes.load(); }
     PlanInstance* current() { return current_; }
@@ -157,7 +167,8 @@ private:
     void SaveTuneCache();
     void EnsurePipeline(PlanInstance& pi, bool allow_tune);
     void AllocInstance(PlanInstance& pi);
-    void PrepareF8();       // quantise the conv weights, calibrate the activation scales, derive the epilogue multipliers (once per DeviceWeights)
+    void RefreshGraphs(PlanInstance& pi);   // (re)capture the graphs of `pi` when they are missing or older than the current fp8 scales
+    void PrepareF8(const std::vector<float>* adopt_act_scales = nullptr);       // quantise the conv weights, calibrate the activation scales, derive the epilogue multipliers (once per DeviceWeights)
     void LaunchStep(const PlanInstance& pi, const Step& s, hipStream_t stream);
     ConvArgs MakeConvArgs(const PlanInstance& pi, const Step& s) const;
 

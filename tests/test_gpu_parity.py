@@ -1108,6 +1108,40 @@ def test_plan_cache_is_bounded(model_repo):
         _run_with_env(dict(IE_MAX_PLANS="2", IE_AUTOTUNE="0"), lambda: go(tmp))
 
 
+def test_output_dims_survive_plan_eviction_under_concurrency(tmp_path):
+    """the sharded / coalesced paths described their outputs from a plan instance AFTER releasing its lane; with a full
+    plan cache another request's Prepare frees that instance.  IE_MAX_PLANS=1, two shard lanes on device 0, three threads alternating
+    batch sizes through the sharded path (rows >= shards) and the single-lane path (rows < shards): every call must report its own
+    dims and its own logits."""
+    mb = models.densenet("N", growth=8, blocks=(2, 2), stem=16, image=32, classes=10, seed=9)
+    path = models.write_repo(str(tmp_path), "evict", mb)
+    xs = {b: models.synthetic_input((b, 3, 32, 32), stream=f"evict{b}") for b in (1, 2, 3, 4, 6)}
+
+    def go():
+        m = B.CreateModel(path, "evict")
+        try:
+            assert B.ShardStats(m)[0] == 2
+            ref = {b: infer(m, "", "data_0", xs[b], "fc6_1", [b, 10, 1, 1])[0].copy() for b in xs}
+            errs = []
+
+            def worker(order):
+                try:
+                    for _ in range(12):
+                        for b in order:
+                            y, dims = infer(m, "", "data_0", xs[b], "fc6_1", [b, 10, 1, 1])
+                            assert dims == [b, 10, 1, 1], (b, dims)
+                            assert rel_err(y, ref[b]) < 2e-5, b
+                except Exception as e:  # noqa: BLE001
+                    errs.append(e)
+            ts = [threading.Thread(target=worker, args=(o,)) for o in ((1, 4, 2, 6, 3), (6, 3, 1, 2, 4), (2, 6, 4, 3, 1))]
+            [t.start() for t in ts]
+            [t.join() for t in ts]
+            assert not errs, errs
+        finally:
+            m.Destroy()
+    _run_with_env(dict(IE_MAX_PLANS="1", IE_AUTOTUNE="0", IE_SHARD_DEVICES="0,0"), go)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # BASELINE.json configs at their own sizes, and the multi-input ordering rule
 # ---------------------------------------------------------------------------------------------------------------------
@@ -1128,7 +1162,7 @@ def test_config2_fp16_densenet121_b128(densenet_repo, tmp_path):
     Other output grids, other kernel choices and multi-round persistent loops than the B=2 / B=32 cases.  Size-independent
     property: each image's logits equal that image run alone (up to fp16 summation-order rounding); plus the float64 oracle
     on 2 of the 128 images, and a batch permutation."""
-    root = _with_precision_config(densenet_repo, tmp_path, ',"precision":"fp16"')
+    root = _with_precision_config(densenet_repo, tmp_path, ',"precision":"fp16","tune_batches":[1,128]')     # the SEARCHED kernel set bench.py times
     mgr = B.NewInferenceManager(root)
     try:
         mgr.LoadModel("densenet_onnx")
@@ -1306,6 +1340,54 @@ def test_rccl_weight_broadcast_to_a_private_replica(densenet_repo):
     assert info3["lane_shares_weights_with"] == [0, 0] and not info3["rccl"]["used"]
 
 
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "fp8"])
+def test_private_replicas_hold_the_primarys_blob_and_every_mirror(tmp_path, prec):
+    """VERDICT r2 #7a, ADVICE r2: four shard lanes on device 0 that each OWN a (zeroed, never uploaded) weight allocation
+    (IE_SHARD_PRIVATE_WEIGHTS=1): after the load-time broadcast + WeightsArrived every replica's fp32 blob AND everything derived from
+    it (half mirror; fragment-major + Winograd U; e4m3 weights, their row scales / epilogue multipliers and the adopted activation
+    scales) must be bit-identical to the primary's, the sharded answer must equal the unsharded one, and an in-place weight update
+    (EngineWeightsUpdated) must reach every owner and every captured graph."""
+    if prec == "fp8":
+        mb, iname, oname = models.resnet("N", layers=(2, 1, 2, 1), width=16, image=64, classes=20, seed=51), "data", "logits"
+        oshape, xshape = [8, 20], (8, 3, 64, 64)
+    else:
+        mb, iname, oname = models.densenet("N", growth=32, blocks=(2, 3, 2), stem=64, image=64, classes=24, seed=78), "data_0", "fc6_1"
+        oshape, xshape = [8, 24, 1, 1], (8, 3, 64, 64)
+    path = models.write_repo(str(tmp_path), "priv", mb)
+    x = models.synthetic_input(xshape, stream="priv")
+
+    def run(update):
+        m = B.CreateModel(path, "priv")
+        try:
+            y = infer(m, "", iname, x, oname, oshape)[0].copy()
+            if update:            # scale the whole blob by 1/2 in place on the primary, tell the engine, run again
+                ptr, nbytes = B.GetWeightBlob(m)
+                w = np.empty(nbytes // 4, np.float32)
+                B.CopyToHost(m, w, ptr)
+                B.CopyToDevice(m, ptr, (w * np.float32(0.5)).astype(np.float32))
+                B.WeightsUpdated(m)
+                y2 = infer(m, "", iname, x, oname, oshape)[0].copy()
+            else:
+                y2 = None
+            return y, y2, B.RuntimeInfo(m, checksums=True), B.ShardStats(m)
+        finally:
+            m.Destroy()
+    y1, y1u, info1, _ = _run_with_env(dict(IE_PRECISION=prec), lambda: run(True))
+    y4, y4u, info4, st = _run_with_env(dict(IE_PRECISION=prec, IE_SHARD_DEVICES="0,0,0,0", IE_SHARD_PRIVATE_WEIGHTS="1"), lambda: run(True))
+    assert info4["lanes"] == 4 and info4["lane_shares_weights_with"] == [0, 1, 2, 3] and st[0] == 4 and st[1] >= 2
+    assert info4["rccl"]["used"] and info4["rccl"]["weight_owners"] == 4
+    assert len(set(info4["weight_checksums"])) == 1 and info4["weight_checksums"][0] == info1["weight_checksums"][0]
+    mc = info4["mirror_checksums"]
+    want = {"fp32": {"fragment_major", "winograd_u"}, "fp16": {"half"}, "fp8": {"half", "e4m3", "e4m3_scales", "act_scales"}}[prec]
+    assert want <= set(mc[0]), mc[0]
+    for k in range(1, 4):
+        assert mc[k] == mc[0], (k, mc[k], mc[0])
+    assert mc[0] == info1["mirror_checksums"][0]
+    tol = {"fp32": 2e-5, "fp16": F16_RTOL, "fp8": F8_EMU_RTOL * 4}[prec]
+    assert rel_err(y4, y1) < tol and rel_err(y4u, y1u) < tol
+    assert rel_err(y1u, y1) > 1e-3            # the update really changed the answer (so stale graphs / stale replicas would show)
+
+
 def test_pipelined_host_path_matches_single_shot(densenet_repo):
     """ModelInfer uploads a batch in image ranges and runs the first plan steps per range while the next range uploads; the rest runs
     once on the whole batch.  Same arithmetic, other tile choices for the per-range launches: equal to the single-shot path up to
@@ -1408,7 +1490,7 @@ def test_requests_never_wait_for_a_kernel_search(tmp_path):
 # (3) the plain float64 oracle: the difference is the e4m3 quantisation error of a 50-layer network; this repo's statement of
 # the tolerance is F8_RTOL of max|ref| (3 mantissa bits per stored tensor, ~3 % RMS per element, averaged by the dot products).
 # ---------------------------------------------------------------------------------------------------------------------
-F8_RTOL = 0.12
+F8_RTOL = 0.08
 F8_EMU_RTOL = 5e-3
 
 
@@ -1500,6 +1582,70 @@ def test_fp8_resnet50_b2_vs_float64_oracle_and_emulation(tmp_path):
     print(f"resnet50 fp8 B=2: vs fp8 emulation {e_emu:.2e}, vs float64 oracle {e_ref:.2e}; top-1 in the oracle's top-5: {hit}; "
           f"top-1 equal: {np.argmax(y, 1).tolist() == np.argmax(ref, 1).tolist()}")
     assert e_emu < F8_RTOL and e_ref < F8_RTOL and all(hit)
+
+
+def test_fp8_resnet50_top1_agreement_over_16_images(tmp_path):
+    """Top-1 of the fp8 engine against the float64 oracle on 16 ResNet-50 images (random-init weights: the winning margin of an image is
+    a few per cent of max|logit|, so this is a sharper check than the norm bound), plus the per-image error bound."""
+    mb = models.resnet50("N")
+    path = models.write_repo(str(tmp_path), "resnet50", mb)
+    x = models.synthetic_input((16, 3, 224, 224), stream="resnet50_top1")
+    ref = O.run(O.load_model(mb), {"data": x}, dtype=np.float64)["logits"]
+    y, _ = _fp8_run(path, "resnet50", x, "data", "logits", [16, 1000])
+    errs = [rel_err(y[i], ref[i]) for i in range(16)]
+    agree = int((np.argmax(y, 1) == np.argmax(ref, 1)).sum())
+    top5 = sum(int(np.argmax(y[i])) in set(np.argsort(ref[i])[-5:]) for i in range(16))
+    print(f"resnet50 fp8 B=16: top-1 agreement {agree}/16, engine top-1 inside the oracle's top-5 {top5}/16, per-image rel err max {max(errs):.2e} median {np.median(errs):.2e}")
+    assert max(errs) < F8_RTOL
+    assert agree >= 15 and top5 == 16           # >= 90 % top-1 agreement
+
+
+def test_config4_fp8_resnet50_b256(tmp_path):
+    """BASELINE configs[4] at its own size: ResNet-50, fp8 mode, batch 256 through ModelInfer (154 MB FLOAT32 payload) with the
+    SEARCHED kernel set ("tune_batches": [1, 256] -- what bench.py times).  Size-independent properties: each image's logits equal
+    that image run alone, batch permutation equivariance; plus the float64 oracle on 2 of the 256 images."""
+    mb = models.resnet50("N")
+    cfg = ('{"name":"resnet50","platform":"onnxruntime_onnx","version":"1","precision":"fp8","tune_batches":[1,256],'
+           '"inputs":[{"name":"data","dims":[3,224,224],"shape":[1,3,224,224],"data_type":"FLOAT32"}],'
+           '"outputs":[{"name":"logits","dims":[1000],"shape":[1,1000],"data_type":"FLOAT32"}]}')
+    models.write_repo(str(tmp_path), "resnet50", mb, config_json=cfg)
+    mgr = B.NewInferenceManager(str(tmp_path))
+    try:
+        mgr.LoadModel("resnet50")
+        x = models.synthetic_input((256, 3, 224, 224), stream="resnet50_b256")
+        y, dims = infer(mgr, "resnet50", "data", x, "logits", [256, 1000])
+        assert dims == [256, 1000] and np.isfinite(y).all()
+        for i in (0, 131, 255):
+            y1, _ = infer(mgr, "resnet50", "data", x[i:i + 1], "logits", [1, 1000])
+            e = rel_err(y1.reshape(1000), y[i])
+            assert e < F8_EMU_RTOL * 4, (i, e)       # same quantisation points, other kernels / summation order: a few flipped e4m3 codes
+        perm = np.random.RandomState(4).permutation(256)
+        yp, _ = infer(mgr, "resnet50", "data", x[perm], "logits", [256, 1000])
+        np.testing.assert_array_equal(yp, y[perm])   # same plan, same kernels: images are independent, bit for bit
+        ref = O.run(O.load_model(mb), {"data": x[[7, 200]]}, dtype=np.float64)["logits"]
+        e = rel_err(y[[7, 200]], ref)
+        print(f"resnet50 fp8 B=256: rel err vs float64 oracle on images 7, 200: {e:.2e}")
+        assert e < F8_RTOL
+    finally:
+        mgr.Shutdown()
+
+
+def test_fp8_inputs_beyond_the_calibrated_range(tmp_path):
+    """Inputs 4x larger than anything the load-time calibration saw: activations exceed the 2x headroom, the +-448 clamp of the
+    re-quantisation saturates some of them.  The engine must degrade, not break: finite logits, no NaN code (0x7f / 0xff) leaking out
+    of a clamp, and an error against the float64 oracle of the SAME scaled input that stays bounded."""
+    mb = models.resnet(3, layers=(2, 1, 2, 1), width=16, image=64, classes=20, seed=51)
+    path = models.write_repo(str(tmp_path), "resnet_f8d", mb)
+    x = models.synthetic_input((3, 3, 64, 64), stream="resnet_f8")
+    om = O.load_model(mb)
+    out = {}
+    for k in (1.0, 4.0, 64.0):
+        ref = O.run(om, {"data": x * np.float32(k)}, dtype=np.float64)["logits"]
+        y, _ = _fp8_run(path, "resnet_f8d", x * np.float32(k), "data", "logits", [3, 20])
+        assert np.isfinite(y).all(), k
+        out[k] = rel_err(y, ref)
+    print(f"fp8 beyond the calibrated range: rel err at 1x {out[1.0]:.2e}, 4x {out[4.0]:.2e}, 64x (saturating) {out[64.0]:.2e}")
+    assert out[1.0] < F8_RTOL and out[4.0] < 0.5      # 64x: everything clamps; the answer is wrong but finite (asserted above)
 
 
 def test_fp8_rejects_graphs_it_cannot_run(densenet_repo):
