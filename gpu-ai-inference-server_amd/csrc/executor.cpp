@@ -80,6 +80,7 @@ DeviceWeights::~DeviceWeights() {
     (void)hipSetDevice(device);
     if (d_weights) (void)hipFree(d_weights);
     if (d_weights16) (void)hipFree(d_weights16);
+    if (d_weights16_frag) (void)hipFree(d_weights16_frag);
     if (d_weights_frag) (void)hipFree(d_weights_frag);
     if (d_weights8) (void)hipFree(d_weights8);
     if (d_f8_aux) (void)hipFree(d_f8_aux);
@@ -142,6 +143,7 @@ DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id, 
         if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsFused();
         if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsWino();
         if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsX6();
+        if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsBlock();
     });
     check(g_kernels_err, "InitKernels");
     fp32_split_ = opt.fp32_split && opt.precision == Precision::F32;
@@ -233,6 +235,24 @@ void DeviceModel::BuildInstance(PlanInstance& pi, const std::vector<std::vector<
             if (precision_ == Precision::F16 || precision_ == Precision::F8) {
                 check(hipMalloc(&w_->d_weights16, std::max<size_t>(w_->weight_floats, 8) * 2), "hipMalloc(weights16)");
                 w_->device_bytes += w_->weight_floats * 2;
+                if (precision_ == Precision::F16) {
+                    // fragment-major mirror of the dense-layer convs (1x1 -> 128 and 3x3 128 -> 32 channels), whatever step they are part of in
+                    // this plan instance: the weights are shared by every plan instance, another batch size may fuse other layers
+                    auto add16 = [&](const Step& st) {
+                        if (st.kind != StepKind::Conv || st.w_off < 0 || st.in.nchw || st.sh != 1 || st.sw != 1) return;
+                        const bool one = st.kh == 1 && st.kw == 1 && st.out.c == 128 && st.in.c % 32 == 0;
+                        const bool three = st.kh == 3 && st.kw == 3 && st.out.c == 32 && st.in.c == 128;
+                        if (one || three) w_->frag16_regions.push_back({st.w_off, int(st.out.c), int(st.kh * st.kw * st.in.c)});
+                    };
+                    for (const Step& st : pi.plan.steps) {
+                        if (st.parts.empty()) add16(st);
+                        else for (const Step& q : st.parts) add16(q);
+                    }
+                    if (!w_->frag16_regions.empty()) {
+                        check(hipMalloc(&w_->d_weights16_frag, std::max<size_t>(w_->weight_floats, 8) * 2), "hipMalloc(weights16_frag)");
+                        w_->device_bytes += w_->weight_floats * 2;
+                    }
+                }
                 if (precision_ == Precision::F8) {
                     check(hipMalloc(&w_->d_weights8, std::max<size_t>(w_->weight_floats, 16)), "hipMalloc(weights8)");
                     check(hipMemset(w_->d_weights8, 0, std::max<size_t>(w_->weight_floats, 16)), "hipMemset(weights8)");
@@ -426,10 +446,14 @@ void DeviceModel::WeightsArrived(const std::vector<float>* adopt_act_scales) {
         }
         check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
     }
-    if (!w_->d_weights16 && !w_->d_weights_frag) return;
+    if (!w_->d_weights16 && !w_->d_weights_frag) return;      // (the fp16 fragment-major mirror only exists beside the half mirror)
     check(hipSetDevice(device_), "hipSetDevice");
     w_->f8_ready = false;
     if (w_->d_weights16) check(LaunchConvertF32ToF16(w_->d_weights, w_->d_weights16, int64_t(w_->weight_floats), stream_), "convert_f32_f16");
+    if (w_->d_weights16_frag)
+        for (const auto& fr : w_->frag16_regions)
+            check(LaunchPermuteWeightsFrag16(static_cast<const char*>(w_->d_weights16) + fr.w_off * 2, static_cast<char*>(w_->d_weights16_frag) + fr.w_off * 2, fr.rows, fr.k,
+                                             stream_), "permute_weights_frag16");
     if (w_->d_weights_frag)
         for (const DeviceWeights::FragRegion& fr : w_->frag_regions)
             check(LaunchPermuteWeightsFrag(w_->d_weights + fr.w_off, w_->d_weights_frag + fr.w_off, fr.cout, fr.kk, fr.cin, stream_), "permute_weights_frag");
@@ -450,6 +474,11 @@ std::vector<std::pair<std::string, uint64_t>> DeviceModel::MirrorChecksums() {
     };
     constexpr uint64_t kBasis = 0xCBF29CE484222325ull;
     if (W.d_weights16) { pull(W.d_weights16, W.weight_floats * 2); out.push_back({"half", fnv(kBasis, host.data(), host.size())}); }
+    if (W.d_weights16_frag) {
+        uint64_t h = kBasis;
+        for (const auto& fr : W.frag16_regions) { pull(static_cast<const char*>(W.d_weights16_frag) + fr.w_off * 2, size_t(fr.rows) * size_t(fr.k) * 2); h = fnv(h, host.data(), host.size()); }
+        out.push_back({"half_fragment_major", h});
+    }
     if (W.d_weights_frag) {        // only the conv regions of the fragment-major blob are ever written
         uint64_t h = kBasis;
         for (const auto& fr : W.frag_regions) {
@@ -741,6 +770,64 @@ void DeviceModel::Autotune(PlanInstance& pi, size_t nsteps, bool allow_search) {
         for (size_t si = 0; si < nsteps && si < pi.plan.steps.size(); ++si) {
             Step& s = pi.plan.steps[si];
             if (s.kind != StepKind::Conv || s.algo == ConvAlgo::Naive || s.algo == ConvAlgo::Stem) continue;
+            if (s.algo == ConvAlgo::DenseBlock) {
+                DenseBlockArgs b;
+                if (s.tile != 0 && MakeBlockArgs(pi, s, &b) && DenseBlockEligible(b)) check(LaunchDenseBlockF16(b, stream_), "dense_block_f16");
+                else for (const Step& q : s.parts) LaunchStep(pi, q, stream_);
+                break;
+            }
+            if (s.algo == ConvAlgo::DenseBlock) {
+                // the parts get their own kernel choices (what runs when the chain kernel declines, and the yardstick); chain vs parts is
+                // one more timed choice (tile 1 = one launch, 0 = the 2n plain launches)
+                PlanInstance tmp;
+                tmp.plan.steps = s.parts;
+                tmp.buffers = pi.buffers;
+                tmp.owned.assign(pi.buffers.size(), 0);
+                tmp.workspace = pi.workspace;
+                tmp.workspace_floats = pi.workspace_floats;
+                tmp.counters = pi.counters;
+                tmp.batch_off = pi.batch_off;
+                for (size_t q = 0; q < tmp.plan.steps.size(); ++q) tmp.plan.steps[q].idx = int(q);
+                Autotune(tmp, tmp.plan.steps.size(), allow_search);
+                for (size_t q = 0; q < s.parts.size(); ++q) { s.parts[q].algo = tmp.plan.steps[q].algo; s.parts[q].tile = tmp.plan.steps[q].tile; s.parts[q].splitk = tmp.plan.steps[q].splitk; }
+                std::vector<int64_t> keyb = {s.in.n * s.in.h * s.in.w, int64_t(s.parts.size()), s.in.c, s.in.h, s.in.w, s.in.pitch, s.in.c_off, int64_t(ConvAlgo::DenseBlock),
+                                             s.pre_scale_off >= 0, s.bias_off >= 0};
+                int choice = -1;
+                {
+                    std::lock_guard<std::mutex> g(w_->tune_mu);
+                    auto hit = w_->tune_cache.find(keyb);
+                    if (hit != w_->tune_cache.end()) choice = hit->second.first;
+                }
+                DenseBlockArgs b;
+                const bool can = MakeBlockArgs(pi, s, &b) && DenseBlockEligible(b);
+                if (choice < 0 && allow_search && can) {
+                    searched = true;
+                    float best[2] = {1e30f, 1e30f};
+                    for (int t = 0; t < 2; ++t) {
+                        Step trial = s;
+                        trial.tile = t;
+                        LaunchStep(pi, trial, stream_);
+                        for (int rep = 0; rep < 3; ++rep) {
+                            if (scrub) check(hipMemsetAsync(scrub, 0, kScrubBytes, stream_), "hipMemsetAsync(scrub)");
+                            check(hipEventRecord(e0, stream_), "hipEventRecord");
+                            LaunchStep(pi, trial, stream_);
+                            check(hipEventRecord(e1, stream_), "hipEventRecord");
+                            check(hipEventSynchronize(e1), "hipEventSynchronize");
+                            float ms = 0;
+                            check(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime");
+                            best[t] = std::min(best[t], ms);
+                        }
+                    }
+                    choice = best[1] <= best[0] ? 1 : 0;
+                    if (std::getenv("IE_TUNE_LOG")) std::fprintf(stderr, "[tune] dense block %s: chain %.1f us, %zu launches %.1f us\n", s.name.c_str(), best[1] * 1e3, s.parts.size(), best[0] * 1e3);
+                    std::lock_guard<std::mutex> g(w_->tune_mu);
+                    w_->tune_cache[keyb] = {choice, 1};
+                    w_->tune_dirty = true;
+                }
+                if (!can) choice = 0;
+                if (choice >= 0) s.tile = choice;
+                continue;
+            }
             if (s.algo == ConvAlgo::DenseFused) {
                 // the parts get their own kernel choices (they are what runs when the fused launcher declines, and the yardstick);
                 // then fused vs split is one more timed choice, cached like the others (tile 1 = fused, 0 = split)
@@ -1100,6 +1187,42 @@ void DeviceModel::SaveTuneCache() {
     else w_->tune_dirty = false;
 }
 
+// Kernel arguments of a dense-block chain step (kernels_block.hip) from its parts: (1x1, 3x3) pairs on one concat buffer.
+bool DeviceModel::MakeBlockArgs(const PlanInstance& pi, const Step& s, DenseBlockArgs* out) const {
+    if (s.parts.size() < 2 || s.parts.size() % 2 || s.parts.size() / 2 > size_t(kMaxBlockLayers) || !w_->d_weights16 || !w_->d_weights16_frag) return false;
+    DenseBlockArgs b;
+    const Step& f1 = s.parts[0];
+    const TensorArg xin = make_arg(pi, f1.in);
+    b.x = reinterpret_cast<_Float16*>(xin.p) - f1.in.c_off;           // pixel row start of the concat buffer (this plan instance's image range)
+    b.pitch = int(f1.in.pitch);
+    b.in_coff = int(f1.in.c_off);
+    b.n = int(f1.in.n); b.h = int(f1.in.h); b.w = int(f1.in.w);
+    b.wfrag16 = static_cast<const _Float16*>(w_->d_weights16_frag);
+    b.w16 = static_cast<const _Float16*>(w_->d_weights16);
+    b.w32 = w_->d_weights;
+    b.nlayers = int(s.parts.size() / 2);
+    auto u = [](int64_t off) { return off >= 0 ? unsigned(off) : 0xffffffffu; };
+    for (int l = 0; l < b.nlayers; ++l) {
+        const Step& c1 = s.parts[size_t(2 * l)];
+        const Step& c3 = s.parts[size_t(2 * l + 1)];
+        bool have1 = false, have3 = false;
+        for (const auto& fr : w_->frag16_regions) { have1 = have1 || fr.w_off == c1.w_off; have3 = have3 || fr.w_off == c3.w_off; }
+        if (!have1 || !have3 || c1.w_off >= (int64_t(1) << 31) || c3.w_off >= (int64_t(1) << 31)) return false;
+        DenseBlockLayer& L = b.layer[l];
+        L.K = int(c1.in.c);
+        L.out_coff = int(c3.out.c_off);
+        L.w1 = unsigned(c1.w_off);
+        L.w3 = unsigned(c3.w_off);
+        L.ps = u(c1.pre_scale_off);
+        L.pt = u(c1.pre_shift_off);
+        L.b1 = u(c1.bias_off);
+        L.b3 = u(c3.bias_off);
+        L.flags = (c1.pre_relu ? 1 : 0) | (c1.relu ? 2 : 0) | (c3.relu ? 4 : 0);
+    }
+    *out = b;
+    return true;
+}
+
 ConvArgs DeviceModel::MakeConvArgs(const PlanInstance& pi, const Step& s) const {
     const float* wb = w_->d_weights;
     auto wp = [&](int64_t off) -> const float* { return off >= 0 ? wb + off : nullptr; };
@@ -1284,6 +1407,7 @@ static std::string kernel_label(const Step& s) {
     switch (s.kind) {
         case StepKind::Conv:
             if (s.algo == ConvAlgo::Naive) return "conv_naive_kernel";
+            if (s.algo == ConvAlgo::DenseBlock) return s.tile != 0 ? "dense_block_f16_kernel<" + std::to_string(s.parts.size() / 2) + " layers>" : "dense_block_parts<" + std::to_string(s.parts.size()) + " launches>";
             if (s.algo == ConvAlgo::DenseFused) return (s.tile >= 4 ? "conv_dense_fused_ws_kernel<t" : "conv_dense_fused_kernel<t") + std::to_string(s.tile) + ">";
             if (s.algo == ConvAlgo::IgemmF8)
                 return "conv_igemm_f8_kernel<" + std::to_string(kIgemmTiles[s.tile].bm) + "x" + std::to_string(kIgemmTiles[s.tile].bn) + ">";

@@ -34,6 +34,9 @@ struct DeviceWeights {
     int device = 0;
     float* d_weights = nullptr;        // packed fp32 blob (what the RCCL broadcast moves)
     void* d_weights16 = nullptr;       // fp16 / fp8 modes: the same blob as halfs, same element offsets
+    void* d_weights16_frag = nullptr;  // fp16 mode: the half conv weights of the dense-block convs again in MFMA-fragment order at the same element offsets (kernels_block.hip)
+    struct Frag16Region { int64_t w_off; int rows, k; };
+    std::vector<Frag16Region> frag16_regions;
     float* d_weights_frag = nullptr;   // fp32 mode: conv weights again in MFMA-fragment order at the same offsets
     void* d_weights8 = nullptr;        // fp8 mode: conv weights as OCP e4m3 bytes at the same element offsets (per-output-channel scaled)
     // fp8 mode: per fp8 conv (keyed by its weight offset) 2 x Cout floats in d_f8_aux: the weight rows' scales, then the epilogue
@@ -171,6 +174,7 @@ private:
     void PrepareF8(const std::vector<float>* adopt_act_scales = nullptr);       // quantise the conv weights, calibrate the activation scales, derive the epilogue multipliers (once per DeviceWeights)
     void LaunchStep(const PlanInstance& pi, const Step& s, hipStream_t stream);
     ConvArgs MakeConvArgs(const PlanInstance& pi, const Step& s) const;
+    bool MakeBlockArgs(const PlanInstance& pi, const Step& s, DenseBlockArgs* out) const;   // false: the step is not a well-formed dense-block chain
 
     std::shared_ptr<const OnnxModel> model_;
     int device_ = 0;

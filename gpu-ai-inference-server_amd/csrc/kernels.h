@@ -142,6 +142,31 @@ hipError_t InitKernelsX6();
 bool ConvDenseFusedEligible(const ConvArgs& a, const FusedArgs& f, int tile);
 hipError_t LaunchConvDenseFused(const ConvArgs& a, const FusedArgs& f, int tile, hipStream_t stream);
 hipError_t InitKernelsFused();
+// fp16 mode: a chain of dense layers (BN -> ReLU -> 1x1 conv K -> 128 -> BN -> ReLU -> 3x3 conv 128 -> 32) per launch, one workgroup per image, the
+// bottleneck tensor kept in LDS (kernels_block.hip).  Weights come from a fragment-major mirror of the half blob (LaunchPermuteWeightsFrag16).
+struct DenseBlockLayer {
+    int K = 0;                         // input channels of the 1x1 (multiple of 32, >= 64): channels [in_coff, in_coff + K) of the pixel row
+    int out_coff = 0;                  // where the 32 new channels go in the pixel row
+    unsigned w1 = 0, w3 = 0;           // element offsets into wfrag16: fragment-major [128][K] and [32][9 * 128] half weights
+    unsigned ps = 0xffffffffu, pt = 0xffffffffu;   // element offsets into w16 of the 1x1's prologue scale / shift (halfs), 0xffffffff = none
+    unsigned b1 = 0xffffffffu, b3 = 0xffffffffu;   // float offsets into w32 of the two biases, 0xffffffff = none
+    int flags = 0;                     // 1: ReLU in the prologue, 2: ReLU after the 1x1, 4: ReLU after the 3x3
+};
+constexpr int kMaxBlockLayers = 24;
+struct DenseBlockArgs {
+    _Float16* x = nullptr;             // block buffer, NHWC halfs
+    int pitch = 0, in_coff = 0;        // halfs per pixel row; first channel the 1x1 convs read
+    int n = 0, h = 0, w = 0;
+    const _Float16* wfrag16 = nullptr;
+    const _Float16* w16 = nullptr;
+    const float* w32 = nullptr;
+    int nlayers = 0;
+    DenseBlockLayer layer[kMaxBlockLayers];
+};
+bool DenseBlockEligible(const DenseBlockArgs& a);
+hipError_t LaunchDenseBlockF16(const DenseBlockArgs& a, hipStream_t stream);
+hipError_t LaunchPermuteWeightsFrag16(const void* src, void* dst, int rows, int K, hipStream_t stream);
+hipError_t InitKernelsBlock();
 // fp8 precision mode (kernels_f8.hip): implicit GEMM on v_mfma_f32_32x32x16_fp8_fp8 over e4m3 NHWC activations and e4m3 weights,
 // fp32 accumulate, per-channel rescale + bias + e4m3 shortcut + ReLU + re-quantisation in the epilogue.  Tiles 0..6 of kIgemmTiles.
 constexpr int kNumConvF8Tiles = 7;

@@ -1211,6 +1211,88 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
         }
     }
 
+    // ---- dense-block chains (fp16, small maps): consecutive dense layers of one concat buffer as ONE step ---------------------------------------
+    // Pattern per layer: step i = 1x1/s1 conv with 128 output channels reading channels [c_off, c_off + K) of a concat buffer into a bottleneck
+    // tensor T, step i+1 = plain 3x3/s1/p1 conv (no prologue, no residual) from T to 32 channels of the SAME concat buffer outside what the
+    // layer reads, T read by nothing else.  A layer touches only its own image, so a workgroup per image walks the whole chain with T in LDS
+    // (kernels_block.hip): DenseNet-121 blocks 3-4 at batch 128 go from 80 launches to 2.  Maps of at most 8 x 32 raster positions (14x14, 7x7).
+    if (precision == Precision::F16 && !std::getenv("IE_NO_DENSE_BLOCK") && !std::getenv("IE_FORCE_ALGO") && !std::getenv("IE_FORCE_TILE")) {
+        auto same_view = [](const View& a, const View& b) {
+            return a.buf == b.buf && a.n == b.n && a.c == b.c && a.h == b.h && a.w == b.w && a.c_off == b.c_off && a.pitch == b.pitch && a.nchw == b.nchw && a.f16 == b.f16;
+        };
+        auto layer_at = [&](size_t i) {
+            if (i + 1 >= plan.steps.size()) return false;
+            const Step& s1 = plan.steps[i];
+            const Step& s3 = plan.steps[i + 1];
+            if (s1.kind != StepKind::Conv || s3.kind != StepKind::Conv || !s1.parts.empty() || !s3.parts.empty()) return false;
+            if (s1.kh != 1 || s1.kw != 1 || s1.sh != 1 || s1.sw != 1 || s1.pt || s1.pl || s1.pb || s1.pr || s1.has_in2 || s1.out.c != 128) return false;
+            if (s3.kh != 3 || s3.kw != 3 || s3.sh != 1 || s3.sw != 1 || s3.pt != 1 || s3.pl != 1 || s3.pb != 1 || s3.pr != 1 || s3.has_in2 || s3.out.c != 32) return false;
+            if (s3.pre_scale_off >= 0 || s1.w_off < 0 || s3.w_off < 0) return false;
+            if (!s1.in.f16 || !s1.out.f16 || !s3.out.f16 || s1.in.nchw || s1.out.nchw || s3.out.nchw) return false;
+            if (!same_view(s3.in, s1.out) || s3.out.buf != s1.in.buf || s3.out.pitch != s1.in.pitch || s1.out.buf == s1.in.buf) return false;
+            if (s3.out.n != s1.in.n || s3.out.h != s1.in.h || s3.out.w != s1.in.w) return false;
+            if (s1.in.c < 64 || s1.in.c % 32 || s1.in.pitch % 8 || s1.in.c_off % 8 || s3.out.c_off % 8) return false;
+            if (s3.out.c_off < s1.in.c_off + s1.in.c && s3.out.c_off + 32 > s1.in.c_off) return false;
+            if ((s1.pre_scale_off >= 0) != (s1.pre_shift_off >= 0)) return false;
+            const int64_t ntiles = (s1.in.h * (s1.in.w + 1) + 31) / 32;
+            if (ntiles > 8) return false;
+            // T must have no other reader: the fused kernel never writes it to memory
+            for (size_t j = i + 2; j < plan.steps.size(); ++j) {
+                const Step& q = plan.steps[j];
+                if (q.in.buf == s1.out.buf || (q.has_in2 && q.in2.buf == s1.out.buf)) return false;
+                if (q.out.buf == s1.out.buf) break;                // the buffer was recycled for another tensor: T was dead by then (liveness pass)
+            }
+            for (size_t o = 0; o < out_vals.size(); ++o) if (view_of(out_vals[o]).buf == s1.out.buf) return false;
+            return true;
+        };
+        std::vector<Step> blocksteps;
+        for (size_t i = 0; i < plan.steps.size();) {
+            size_t n = 0;
+            while (n < 24 && layer_at(i + 2 * n)) {
+                if (n > 0) {
+                    const Step& f1 = plan.steps[i], &c1 = plan.steps[i + 2 * n], &p3 = plan.steps[i + 2 * n - 1];
+                    if (c1.in.buf != f1.in.buf || c1.in.pitch != f1.in.pitch || c1.in.c_off != f1.in.c_off || c1.in.n != f1.in.n || c1.in.h != f1.in.h || c1.in.w != f1.in.w)
+                        break;
+                    // a layer's first 64 input channels are requested while the previous layer's 3x3 still runs: they must not be its output
+                    if (p3.out.c_off < c1.in.c_off + 64 && p3.out.c_off + 32 > c1.in.c_off) break;
+                }
+                ++n;
+            }
+            if (n == 0) { blocksteps.push_back(plan.steps[i]); ++i; continue; }
+            Step f = plan.steps[i];
+            f.algo = ConvAlgo::DenseBlock;
+            f.tile = 1;
+            f.splitk = 1;
+            f.flops = 0;
+            f.bytes = 0;
+            f.parts.clear();
+            for (size_t q = 0; q < 2 * n; ++q) {
+                const Step& ps = plan.steps[i + q];
+                f.parts.push_back(ps);
+                f.flops += ps.flops;
+                f.bytes += ps.bytes;       // SURVEY §8d's per-conv accounting (the bottleneck tensor's write + read is in it although it stays on-chip here)
+            }
+            f.name = plan.steps[i].name + " ... " + plan.steps[i + 2 * n - 1].name;
+            f.out = plan.steps[i + 2 * n - 1].out;             // what the step leaves in memory last (every part's slice is produced by this step)
+            blocksteps.push_back(std::move(f));
+            i += 2 * n;
+        }
+        if (blocksteps.size() != plan.steps.size()) {
+            std::vector<int> remap(plan.steps.size(), -1);
+            for (size_t k = 0; k < blocksteps.size(); ++k) {
+                if (blocksteps[k].algo == ConvAlgo::DenseBlock) for (const Step& q : blocksteps[k].parts) remap[size_t(q.idx)] = int(k);
+                else remap[size_t(blocksteps[k].idx)] = int(k);
+            }
+            for (size_t k = 0; k < blocksteps.size(); ++k) {
+                Step& st = blocksteps[k];
+                st.idx = int(k);
+                if (st.in_src >= 0) st.in_src = remap[size_t(st.in_src)];
+                if (st.in2_src >= 0) st.in2_src = remap[size_t(st.in2_src)];
+            }
+            plan.steps = std::move(blocksteps);
+        }
+    }
+
     // ---- I/O descriptors ---------------------------------------------------------------------------
     for (size_t i = 0; i < m.inputs.size(); ++i) {
         IoDesc d;
@@ -1254,7 +1336,7 @@ static std::string json_escape(const std::string& s) {
 
 std::string PlanToJson(const Plan& p) {
     static const char* kinds[] = {"conv", "pool", "gap", "eltwise", "copy"};
-    static const char* algos[] = {"igemm_vec", "igemm_scalar", "naive", "raster3x3", "ws1x1", "ws3x3", "stem", "direct", "igemm_f8", "dense_fused", "wino3x3", "conv1x1_x6"};
+    static const char* algos[] = {"igemm_vec", "igemm_scalar", "naive", "raster3x3", "ws1x1", "ws3x3", "stem", "direct", "igemm_f8", "dense_fused", "wino3x3", "conv1x1_x6", "dense_block"};
     std::ostringstream o;
     o.precision(17);
     o << "{\"inputs\":[";

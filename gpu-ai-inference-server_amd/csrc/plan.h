@@ -53,7 +53,9 @@ enum class ConvAlgo : int {
     IgemmF8 = 8,      // fp8 mode: implicit GEMM over e4m3 activations / weights (v_mfma_f32_32x32x16_fp8_fp8)
     DenseFused = 9,   // fp32: 3x3 growth conv of dense layer L + 1x1 bottleneck conv of layer L+1 in one launch (Step::parts holds the two convs)
     Wino3x3 = 10,     // fp32: Winograd F(2x2, 3x3) for 3x3/s1/p1 convs with 32 output channels on even-sized images (2.25x fewer MACs)
-    X6 = 11           // fp32 1x1 conv on the bf16 matrix pipe with exactly split operands (kernels_x6.hip; opt-in IE_FP32_SPLIT=1)
+    X6 = 11,          // fp32 1x1 conv on the bf16 matrix pipe with exactly split operands (kernels_x6.hip; opt-in IE_FP32_SPLIT=1)
+    DenseBlock = 12   // fp16: a chain of dense layers (1x1 K -> 128, 3x3 128 -> 32) in ONE launch, one workgroup per image, the bottleneck tensor
+                      // kept in LDS (kernels_block.hip).  Step::parts = the 2n conv steps as the planner emitted them; tile 1 = fused, 0 = the parts
 };
 
 struct Step {
