@@ -771,12 +771,6 @@ void DeviceModel::Autotune(PlanInstance& pi, size_t nsteps, bool allow_search) {
             Step& s = pi.plan.steps[si];
             if (s.kind != StepKind::Conv || s.algo == ConvAlgo::Naive || s.algo == ConvAlgo::Stem) continue;
             if (s.algo == ConvAlgo::DenseBlock) {
-                DenseBlockArgs b;
-                if (s.tile != 0 && MakeBlockArgs(pi, s, &b) && DenseBlockEligible(b)) check(LaunchDenseBlockF16(b, stream_), "dense_block_f16");
-                else for (const Step& q : s.parts) LaunchStep(pi, q, stream_);
-                break;
-            }
-            if (s.algo == ConvAlgo::DenseBlock) {
                 // the parts get their own kernel choices (what runs when the chain kernel declines, and the yardstick); chain vs parts is
                 // one more timed choice (tile 1 = one launch, 0 = the 2n plain launches)
                 PlanInstance tmp;
@@ -1200,6 +1194,7 @@ bool DeviceModel::MakeBlockArgs(const PlanInstance& pi, const Step& s, DenseBloc
     b.wfrag16 = static_cast<const _Float16*>(w_->d_weights16_frag);
     b.w16 = static_cast<const _Float16*>(w_->d_weights16);
     b.w32 = w_->d_weights;
+    b.w16_bytes = uint64_t(w_->weight_floats) * 2;
     b.nlayers = int(s.parts.size() / 2);
     auto u = [](int64_t off) { return off >= 0 ? unsigned(off) : 0xffffffffu; };
     for (int l = 0; l < b.nlayers; ++l) {
@@ -1280,6 +1275,12 @@ void DeviceModel::LaunchStep(const PlanInstance& pi, const Step& s_in, hipStream
     auto wp = [&](int64_t off) -> const float* { return off >= 0 ? wb + off : nullptr; };
     switch (s.kind) {
         case StepKind::Conv: {
+            if (s.algo == ConvAlgo::DenseBlock) {
+                DenseBlockArgs b;
+                if (s.tile != 0 && MakeBlockArgs(pi, s, &b) && DenseBlockEligible(b)) check(LaunchDenseBlockF16(b, stream_), "dense_block_f16");
+                else for (const Step& q : s.parts) LaunchStep(pi, q, stream_);
+                break;
+            }
             if (s.algo == ConvAlgo::DenseFused) {
                 // one launch for the 3x3 of dense layer L and the 1x1 of layer L+1; the two plain steps when the fused kernel declines
                 const Step& s3 = s.parts.at(0);

@@ -159,8 +159,10 @@ struct DenseBlockArgs {
     int n = 0, h = 0, w = 0;
     const _Float16* wfrag16 = nullptr;
     const _Float16* w16 = nullptr;
+    uint64_t w16_bytes = 0;            // size of each of the two half blobs (buffer descriptors: < 2 GiB)
     const float* w32 = nullptr;
     int nlayers = 0;
+    long long* dbg = nullptr;          // probes only: per-phase cycle sums of workgroup 0 / wave 0 (1x1 loop, weight DMA + 1x1 epilogue, 3x3, closing barrier)
     DenseBlockLayer layer[kMaxBlockLayers];
 };
 bool DenseBlockEligible(const DenseBlockArgs& a);

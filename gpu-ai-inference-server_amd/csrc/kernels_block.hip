@@ -19,6 +19,9 @@
 // Arithmetic replaced: the dense-block part of Ort::Session::Run (inference_engine/src/model.cpp:1264-1270).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace ie {
@@ -30,33 +33,64 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
+// s_setprio(1) for the producer waves, A/B'd in the probe: 355 vs 323 us per 24-layer chain at batch 128 (the raised priority also slows the
+// consumers' epilogue and 3x3, where the producers have nothing to hide): off.
+#ifndef IE_BLOCK_PRIO
+#define IE_BLOCK_PRIO 0
+#endif
+
 namespace {
 constexpr int kTPitch = 136;      // halfs per raster row of T: 128 channels + 8 (272 B = 17 x 16 B: conflict-free ds_read_b128 over consecutive rows)
 constexpr int kAPitch = 72;       // halfs per staged activation row: 64 channels + 8 (144 B = 9 x 16 B)
-constexpr int kBBytes = 16384;    // one 64-deep K chunk of the 1x1 weights: 4 k-steps x 4 N-tiles x 1 KiB
 constexpr int kW3Bytes = 73728;   // all 3x3 weights of a layer: 72 k-steps x 1 KiB
+constexpr int kMaxK = 2048;       // most input channels of a 1x1: its prologue scale + shift (2 K halfs) are staged by 512 threads x 8 halfs
 constexpr unsigned kOOB = 0x80000000u;
 }  // namespace
 
-// CFG 0: up to 8 position tiles per image (14x14 maps): 1x1 waves = 4 (M) x 2 (N), each 2 x 2 tiles of 32 x 32; the 3x3 weights alias the 1x1 staging.
-// CFG 1: up to 2 position tiles per image (7x7 maps):  1x1 waves = 2 (M) x 4 (N), each 1 x 1 tile; the 3x3 weights have LDS of their own.
+// max(v, lo) per half without the canonicalising second v_pk_max_f16 that __builtin_elementwise_max emits (the inputs are results of an fma:
+// already canonical)
+__device__ __forceinline__ h8 pk_max8(h8 v, h8 lo) {
+    u32x4 x = __builtin_bit_cast(u32x4, v);
+    const u32x4 l = __builtin_bit_cast(u32x4, lo);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm("v_pk_max_f16 %0, %1, %2" : "=v"(x[k]) : "v"(x[k]), "v"(l[k]));
+    return __builtin_bit_cast(h8, x);
+}
+
+// CFG 0: up to 7 position tiles per image (14x14 maps: 210 raster positions); CFG 1: up to 2 (7x7 maps).
+//
+// Wave specialisation (the third build; what the first two measured is in DESIGN.md): with all eight waves doing everything -- wait for loads,
+// prologue, ds_write, issue, barrier, MFMAs -- a 64-channel chunk cost 3.2 k cycles for 1.0 k cycles of MFMAs, because the barrier puts every wave
+// in the same phase and the phases add up.  Now
+//   * waves 4-7 (PRODUCERS) move data: chunk c + 1's pixel rows registers -> (BN+ReLU as packed half math) -> LDS and chunk c + 3's loads, the
+//     layer's 3x3 weights (held in registers across the 1x1 loop, written to LDS behind it), the next layer's constants;
+//   * waves 0-3 (CONSUMERS) only multiply: wave w owns the 32 bottleneck channels of N tile w for ALL position tiles (7 accumulators), takes its
+//     weight fragments straight from L2 into a register ring (1 KiB contiguous each in the fragment-major mirror, fetched by exactly one wave)
+//     and its activation fragments from the LDS chunk the producers finished one barrier earlier;
+//   * one barrier per chunk; a producer wave shares its SIMD with a consumer wave, so its VALU / LDS-write / load-issue slots fill the gaps of the
+//     consumer's MFMA stream instead of standing in front of them.
+// Every load of a ring is a buffer load issued UNCONDITIONALLY (a chunk index past the layer's end becomes out-of-range offsets, which return
+// zeros without touching memory): the queue looks the same on every path, so the compiler's vmcnt counts stay exact -- one conditional issue and
+// every wait in the loop collapses to "all outstanding loads".
 template <int CFG>
 __global__ __launch_bounds__(512) void dense_block_f16_kernel(const DenseBlockArgs a) {
-    constexpr int WM1 = CFG == 0 ? 4 : 2, TM1 = CFG == 0 ? 2 : 1, WN1 = 8 / WM1, TN1 = 4 / WN1;
-    constexpr int PIT = CFG == 0 ? 4 : 1;                  // staged rows per thread and chunk (64 rows per pass of the 512 threads)
-    constexpr bool kAlias = CFG == 0;
+    constexpr int TM = CFG == 0 ? 7 : 2;                   // position tiles per image at most
+    constexpr int PITP = CFG == 0 ? 7 : 2;                 // 16-byte pieces per producer thread and chunk (rows tp / 8 + 32 i)
+    constexpr int T3 = CFG == 0 ? 2 : 1;                   // 3x3: position tiles per consumer wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_blk[];
 
     const int H = a.h, W = a.w, PW = W + 1, NP = H * PW;
-    const int ntiles = (NP + 31) >> 5, M1p = ntiles * 32;
+    const int ntiles = (NP + 31) >> 5;
     const int trows = NP + 2 * PW + 2;
     _Float16* const sT = reinterpret_cast<_Float16*>(smem_blk);                              // [trows][kTPitch]
-    unsigned char* const sS = smem_blk + size_t(trows) * kTPitch * 2;                        // staging
-    _Float16* const sB[2] = {reinterpret_cast<_Float16*>(sS), reinterpret_cast<_Float16*>(sS + kBBytes)};
-    _Float16* const sA[2] = {reinterpret_cast<_Float16*>(sS + 2 * kBBytes), reinterpret_cast<_Float16*>(sS + 2 * kBBytes + size_t(M1p) * kAPitch * 2)};
-    unsigned char* const sEnd = sS + 2 * kBBytes + size_t(2) * M1p * kAPitch * 2;
-    _Float16* const sW3 = reinterpret_cast<_Float16*>(kAlias ? sS + kBBytes : sEnd);        // aliases sB[1] + sA[*] (CFG 0) or follows the staging
-    float* const sBias = reinterpret_cast<float*>(kAlias ? sEnd : sEnd + kW3Bytes);          // [128] 1x1 bias, [32] 3x3 bias
+    unsigned char* const sS = smem_blk + size_t(trows) * kTPitch * 2;                        // staging: two activation chunks; then all 3x3 weights
+    _Float16* const sA0 = reinterpret_cast<_Float16*>(sS);
+    _Float16* const sA1 = reinterpret_cast<_Float16*>(sS + size_t(32 * TM) * kAPitch * 2);      // (always 32 x TM rows: no per-row guards)
+    _Float16* const sW3 = reinterpret_cast<_Float16*>(sS);
+    const size_t stage_bytes = size_t(kW3Bytes);                                          // >= 2 x 224 x 144 B
+    // per-layer constants, double-buffered by layer parity (the next layer's are staged while this layer's 3x3 runs)
+    float* const sBias0 = reinterpret_cast<float*>(sS + stage_bytes);                        // [2][160]: [128] 1x1 bias, [32] 3x3 bias
+    _Float16* const sPre0 = reinterpret_cast<_Float16*>(sBias0 + 2 * 160);                   // [2][2][kMaxK]: prologue scale, shift
 
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -64,242 +98,357 @@ __global__ __launch_bounds__(512) void dense_block_f16_kernel(const DenseBlockAr
     const int pitch = a.pitch;
     _Float16* const ximg = a.x + size_t(img) * H * W * pitch;
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(ximg, 0, H * W * pitch * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wf = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.wfrag16), 0, int(a.w16_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w16 = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.w16), 0, int(a.w16_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w32 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w32), 0, int(a.w16_bytes * 2 < 0x7fffffffull ? a.w16_bytes * 2 : 0x7fffffffull), 0x00020000);
 
     // ---- zero the raster once: pad rows / columns are never written again ----
     {
         const int n16 = trows * kTPitch / 8;
         for (int q = tid; q < n16; q += 512) reinterpret_cast<u32x4*>(sT)[q] = u32x4{0u, 0u, 0u, 0u};
     }
+    const int nl = a.nlayers;
 
-    // ---- staging geometry: thread -> (row l = tid / 8 + 64 i, 8 channels at c8) ----
-    const int c8 = (tid & 7) * 8;
-    int poff[PIT];                     // element offset of (pixel, c8) inside the image, or -1 (pad column, position past the image)
+    if (wave >= 4) {
+        // =========================================== PRODUCERS ===========================================
+        if (IE_BLOCK_PRIO) __builtin_amdgcn_s_setprio(1);  // data movers first: their VALU / LDS / load-issue slots fill the gaps of the consumers' MFMA stream
+        const int tp = tid - 256;
+        const int c8 = (tp & 7) * 8;
+        int poff[PITP];                // element offset of (pixel, c8) inside the image, or -1 (pad column, position past the image)
 #pragma unroll
-    for (int i = 0; i < PIT; ++i) {
-        const int p = (tid >> 3) + 64 * i;
-        const int y = p / PW, x = p - y * PW;
-        poff[i] = (p < NP && x < W) ? (y * W + x) * pitch + a.in_coff + c8 : -1;
-    }
-    // ---- 1x1 wave tile and per-lane validity of its positions ----
-    const int mp = wave % WM1, np = wave / WM1;
-    bool valid1[TM1];
-    int trow1[TM1];                    // raster row of T the lane's pixel goes to
-#pragma unroll
-    for (int i = 0; i < TM1; ++i) {
-        const int p = (mp * TM1 + i) * 32 + r;
-        const int y = p / PW, x = p - y * PW;
-        valid1[i] = p < NP && x < W;
-        trow1[i] = p + PW + 1;
-    }
-    // ---- 3x3: wave w owns position tile w ----
-    const int p3 = wave * 32 + r;
-    const int y3 = p3 / PW, x3 = p3 - y3 * PW;
-    const bool valid3 = wave < ntiles && p3 < NP && x3 < W;
-    const unsigned orow3 = valid3 ? unsigned((y3 * W + x3) * pitch) * 2u : kOOB;
-
-    u32x4 av[PIT];
-    u32x4 sv, tv;                      // prologue scale / shift of this thread's 8 channels
-    auto issue_a = [&](const DenseBlockLayer& L, int c) {
-        const int cb = c * 64 + c8;
-        const bool cok = cb < L.K;
-#pragma unroll
-        for (int i = 0; i < PIT; ++i) {
-            const unsigned off = (poff[i] >= 0 && cok) ? unsigned(poff[i] + c * 64) * 2u : kOOB;
-            av[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
+        for (int i = 0; i < PITP; ++i) {
+            const int p = (tp >> 3) + 32 * i;
+            const int y = p / PW, x = p - y * PW;
+            poff[i] = (p < NP && x < W) ? (y * W + x) * pitch + a.in_coff + c8 : -1;
         }
-        if (L.ps != 0xffffffffu) {
-            const int cc = cok ? cb : 0;
-            sv = *reinterpret_cast<const u32x4*>(a.w16 + L.ps + cc);
-            tv = *reinterpret_cast<const u32x4*>(a.w16 + L.pt + cc);
-        }
-    };
-    auto issue_b = [&](const DenseBlockLayer& L, int c, int buf) {
-        const int nblk = (L.K - c * 64 >= 64 ? 4 : 2) * 4;                      // 1 KiB fragment blocks of this chunk
-        const _Float16* const src = a.wfrag16 + L.w1 + size_t(c) * 16 * 512;
-        for (int q = wave; q < nblk; q += 8)
-            __builtin_amdgcn_global_load_lds(src + q * 512 + lane * 8, sB[buf] + q * 512, 16, 0, 0);
-    };
-    auto commit_a = [&](const DenseBlockLayer& L, int buf) {
-        const bool pre = L.ps != 0xffffffffu;
-        const h8 s8 = __builtin_bit_cast(h8, sv), t8 = __builtin_bit_cast(h8, tv);
+        struct ASlot { u32x4 v[PITP]; };
+        ASlot ra[3];
+        u32x4 w3r[18];                 // this thread's 288 bytes of the layer's 3x3 weights, held across the 1x1 loop
+        u32x4 cpre[2];
+        float cbias = 0.f;
+        auto issue = [&](ASlot& A, const DenseBlockLayer& L, int c) {
+            const bool cok = c * 64 + c8 < L.K;
 #pragma unroll
-        for (int i = 0; i < PIT; ++i) {
-            const int l = (tid >> 3) + 64 * i;
-            h8 v = __builtin_bit_cast(h8, av[i]);
-            if (pre) {
-                v = v * s8 + t8;
-                if (L.flags & 1) v = __builtin_elementwise_max(v, h8{});
+            for (int i = 0; i < PITP; ++i)
+                A.v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (poff[i] >= 0 && cok) ? unsigned(poff[i] + c * 64) * 2u : kOOB, 0, 0);
+        };
+        auto issue_w3 = [&](const DenseBlockLayer& L) {
+#pragma unroll
+            for (int q = 0; q < 18; ++q) w3r[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_wf, (L.w3 + unsigned(q * 256 + tp) * 8u) * 2u, 0, 0);
+        };
+        // constants of a layer: two 16-byte pieces of (scale | shift) and one bias float per thread
+        auto fetch_consts = [&](const DenseBlockLayer& L) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = tp + 256 * j, half = q * 8 < L.K ? 0 : 1, off = q * 8 - half * L.K;
+                const bool ok = L.ps != 0xffffffffu && off < L.K;
+                cpre[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w16, ok ? ((half ? L.pt : L.ps) + unsigned(off)) * 2u : kOOB, 0, 0);
             }
-            if (l < M1p) *reinterpret_cast<h8*>(sA[buf] + l * kAPitch + c8) = v;
-        }
-    };
-
-    f32x16 acc[TM1][TN1];
-    auto zero_acc = [&]() {
+            const unsigned bo = tp < 128 ? L.b1 : L.b3;
+            cbias = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_w32, (tp < 160 && bo != 0xffffffffu) ? (bo + unsigned(tp < 128 ? tp : tp - 128)) * 4u : kOOB, 0, 0));
+        };
+        auto store_consts = [&](const DenseBlockLayer& L, int par) {
 #pragma unroll
-        for (int i = 0; i < TM1; ++i)
-#pragma unroll
-            for (int j = 0; j < TN1; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    };
-    auto compute1 = [&](int buf, int nks) {
-        const _Float16* const Ab = sA[buf] + (mp * TM1 * 32 + r) * kAPitch + hh * 8;
-        const _Float16* const Bb = sB[buf] + (np * TN1) * 512 + lane * 8;
-        for (int s = 0; s < nks; ++s) {
-            h8 af[TM1], bf[TN1];
-#pragma unroll
-            for (int i = 0; i < TM1; ++i) {            // a tile past the image (7 tiles over 4 x 2) has no staged rows: feed zeros
-                af[i] = h8{};
-                if (mp * TM1 + i < ntiles) af[i] = *reinterpret_cast<const h8*>(Ab + i * 32 * kAPitch + s * 16);
+            for (int j = 0; j < 2; ++j) {
+                const int q = tp + 256 * j, half = q * 8 < L.K ? 0 : 1, off = q * 8 - half * L.K;
+                if (off < L.K) {
+                    // no prologue: scale 1 (0x3c00), shift 0 -- the commit loop is branch-free
+                    const u32x4 ident = half ? u32x4{0u, 0u, 0u, 0u} : u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+                    *reinterpret_cast<u32x4*>(sPre0 + (par * 2 + half) * kMaxK + off) = L.ps != 0xffffffffu ? cpre[j] : ident;
+                }
             }
+            if (tp < 160) sBias0[par * 160 + tp] = cbias;
+        };
+        // Branch-free: a layer without a prologue has scale 1 / shift 0 staged (store_consts), ReLU is a select on a wave-uniform flag folded into
+        // the clamp value, every thread's rows exist in the staging buffer (it always holds 32 x PITP rows).
+        auto commit = [&](const ASlot& A, const DenseBlockLayer& L, const _Float16* sPre, int c) {
+            _Float16* const dst = (c & 1) ? sA1 : sA0;
+            const int cb = c * 64 + c8 < L.K ? c * 64 + c8 : 0;
+            const h8 s8 = *reinterpret_cast<const h8*>(sPre + cb), t8 = *reinterpret_cast<const h8*>(sPre + kMaxK + cb);
+            const _Float16 lo = (L.flags & 1) ? _Float16(0.f) : _Float16(-65504.f);
+            const h8 lo8 = {lo, lo, lo, lo, lo, lo, lo, lo};
 #pragma unroll
-            for (int j = 0; j < TN1; ++j) bf[j] = *reinterpret_cast<const h8*>(Bb + (s * 4 + j) * 512);
-#pragma unroll
-            for (int i = 0; i < TM1; ++i)
-#pragma unroll
-                for (int j = 0; j < TN1; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
-        }
-    };
-
-    const DenseBlockLayer& L0 = a.layer[0];
-    issue_a(L0, 0);
-    issue_b(L0, 0, 0);
-    __syncthreads();                                       // raster zeroed before anybody writes T
-
-    for (int li = 0; li < a.nlayers; ++li) {
-        const DenseBlockLayer& L = a.layer[li];
-        const int K = L.K, NC = (K + 63) >> 6;
-        if (tid < 128) sBias[tid] = L.b1 != 0xffffffffu ? a.w32[L.b1 + tid] : 0.f;
-        else if (tid < 160) sBias[tid] = L.b3 != 0xffffffffu ? a.w32[L.b3 + tid - 128] : 0.f;
-        zero_acc();
-        // ---------------- 1x1: K -> 128 over all positions of the image ----------------
-        for (int c = 0; c < NC; ++c) {
-            const int buf = c & 1;
-            commit_a(L, buf);
-            __syncthreads();                               // chunk c staged (activations written, weight DMA landed: the barrier drains vmcnt)
-            if (c + 1 < NC) {
-                issue_a(L, c + 1);
-                issue_b(L, c + 1, buf ^ 1);
+            for (int i = 0; i < PITP; ++i) {
+                const int l = (tp >> 3) + 32 * i;
+                h8 v = __builtin_bit_cast(h8, A.v[i]) * s8 + t8;
+                v = pk_max8(v, lo8);
+                *reinterpret_cast<h8*>(dst + l * kAPitch + c8) = v;
             }
-            if (mp * TM1 < ntiles) compute1(buf, K - c * 64 >= 64 ? 4 : 2);
+        };
+        const bool stamp = a.dbg != nullptr && blockIdx.x == 0 && wave == 4;
+        long long tp_[6] = {0, 0, 0, 0, 0, 0};
+        fetch_consts(a.layer[0]);
+        issue(ra[0], a.layer[0], 0);
+        issue(ra[1], a.layer[0], 1);
+        issue(ra[2], a.layer[0], 2);
+        issue_w3(a.layer[0]);
+        store_consts(a.layer[0], 0);
+        __syncthreads();                                   // raster zeroed, first constants in place
+        for (int li = 0; li < nl; ++li) {
+            const DenseBlockLayer& L = a.layer[li];
+            const int NC = (L.K + 63) >> 6;
+            const _Float16* const sPre = sPre0 + (li & 1) * 2 * kMaxK;
+            auto step = [&](ASlot& A, int c) {
+                long long u0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+                commit(A, L, sPre, c);                     // waits for chunk c's loads only
+                if (stamp) { const long long u1 = __builtin_amdgcn_s_memtime(); tp_[0] += u1 - u0; u0 = u1; }
+                issue(A, L, c + 3);
+                if (stamp) { const long long u1 = __builtin_amdgcn_s_memtime(); tp_[1] += u1 - u0; u0 = u1; }
+                __syncthreads();                           // chunk c staged (the consumers are past compute(c - 2): this buffer was free)
+                if (stamp) { const long long u1 = __builtin_amdgcn_s_memtime(); tp_[2] += u1 - u0; }
+            };
+            long long v0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+            int c0 = 0;
+            for (; c0 + 3 <= NC; c0 += 3) {
+                step(ra[0], c0);
+                step(ra[1], c0 + 1);
+                step(ra[2], c0 + 2);
+            }
+            if (c0 < NC) step(ra[0], c0);
+            if (c0 + 1 < NC) step(ra[1], c0 + 1);
+            __syncthreads();                               // the consumers are done with the last chunk: the staging area is free
+            if (stamp) { const long long v1 = __builtin_amdgcn_s_memtime(); tp_[3] += v1 - v0; v0 = v1; }
+#pragma unroll
+            for (int q = 0; q < 18; ++q) *reinterpret_cast<u32x4*>(sW3 + (q * 256 + tp) * 8) = w3r[q];
+            __syncthreads();                               // 3x3 weights in place (and the consumers' T raster)
+            if (stamp) { const long long v1 = __builtin_amdgcn_s_memtime(); tp_[4] += v1 - v0; v0 = v1; }
+            {       // the next layer's first chunks, 3x3 weights and constants on their way while the consumers run the 3x3
+                    // (behind the last layer the first one's are requested again and never used: the queue must look the same on every path)
+                const DenseBlockLayer& Ln = a.layer[li + 1 < nl ? li + 1 : 0];
+                fetch_consts(Ln);
+                issue(ra[0], Ln, 0);
+                issue(ra[1], Ln, 1);
+                issue(ra[2], Ln, 2);
+                issue_w3(Ln);
+                store_consts(Ln, (li + 1) & 1);
+            }
+            __syncthreads();                               // layer done: T and the 3x3 weights are free, the new channels are visible
+            if (stamp) { const long long v1 = __builtin_amdgcn_s_memtime(); tp_[5] += v1 - v0; }
         }
-        __syncthreads();                                   // every wave is done with the staging buffers
-        // ---------------- 3x3 weights by LDS-DMA while the 1x1 epilogue runs ----------------
-        {
-            const _Float16* const src = a.wfrag16 + L.w3;
-            for (int q = wave; q < 72; q += 8) __builtin_amdgcn_global_load_lds(src + q * 512 + lane * 8, sW3 + q * 512, 16, 0, 0);
+        if (stamp && lane == 0)
+            for (int q = 0; q < 6; ++q) a.dbg[8 + q] = tp_[q];
+    } else {
+        // =========================================== CONSUMERS ===========================================
+        const int np = wave;                               // N tile of the 1x1: bottleneck channels 32 np .. 32 np + 31
+        unsigned vmask = 0;                                // bit i: this lane's position of tile i is a pixel of the image
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int p = i * 32 + r;
+            const int y = p / PW, x = p - y * PW;
+            if (p < NP && x < W) vmask |= 1u << i;
         }
-        // ---------------- 1x1 epilogue: bias + ReLU -> half -> T raster (valid positions only) ----------------
+        unsigned orow3[T3];                                // 3x3: byte offset of the lane's output pixel row, or out of range
 #pragma unroll
-        for (int i = 0; i < TM1; ++i)
+        for (int j = 0; j < T3; ++j) {
+            const int t = (CFG == 0 ? wave * T3 : wave) + j;
+            const int p = t * 32 + r;
+            const int y = p / PW, x = p - y * PW;
+            orow3[j] = (t < ntiles && (CFG == 0 || wave < 2) && p < NP && x < W) ? unsigned((y * W + x) * pitch) * 2u : kOOB;
+        }
+        struct BSlot { u32x4 f[4]; };
+        BSlot bs[3];
+        auto issue_b = [&](BSlot& Bq, const DenseBlockLayer& L, int c) {
+            const int nks = (L.K - c * 64) >> 4;           // <= 0 past the layer; 2 in the last chunk of a K % 64 == 32 layer
+            const unsigned base = (L.w1 + (unsigned(c) * 16u + unsigned(np)) * 512u + unsigned(lane) * 8u) * 2u;
 #pragma unroll
-            for (int j = 0; j < TN1; ++j) {
-                const int nt = np * TN1 + j;
-                float v[16];
+            for (int s = 0; s < 4; ++s) Bq.f[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_wf, s < nks ? base + unsigned(s) * 4096u : kOOB, 0, 0);
+        };
+        f32x16 acc[TM];
+        // One chunk: TM position tiles x NKS k-steps as ONE straight line (no runtime tile count inside: a branch per tile made the compiler
+        // serialise read -> wait -> MFMA, 2.2 k cycles per chunk for 0.9 k of MFMAs; tiles past the image multiply staging rows nobody reads
+        // back).  Activation fragments come through a ring of four registers, read three MFMAs ahead of their use.
+        auto compute_n = [&](const BSlot& Bq, int c, auto nks_c) {
+            constexpr int NKS = decltype(nks_c)::value, NST = NKS * TM, AHEAD = 3;
+            const _Float16* const Ab = ((c & 1) ? sA1 : sA0) + r * kAPitch + hh * 8;
+            h8 af[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 bq = *reinterpret_cast<const f32x4*>(sBias + nt * 32 + 8 * g + 4 * hh);
+            for (int q = 0; q < AHEAD && q < NST; ++q) af[q & 3] = *reinterpret_cast<const h8*>(Ab + (q % TM) * 32 * kAPitch + (q / TM) * 16);
+            __builtin_amdgcn_sched_group_barrier(0x100, AHEAD < NST ? AHEAD : NST, 0);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float x = acc[i][j][4 * g + q] + bq[q];
-                        v[4 * g + q] = (L.flags & 2) ? fmaxf(x, 0.f) : x;
+            for (int q = 0; q < NST; ++q) {
+                if (q + AHEAD < NST) af[(q + AHEAD) & 3] = *reinterpret_cast<const h8*>(Ab + ((q + AHEAD) % TM) * 32 * kAPitch + ((q + AHEAD) / TM) * 16);
+                acc[q % TM] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, Bq.f[q / TM]), af[q & 3], acc[q % TM], 0, 0, 0);
+                if (q + AHEAD < NST) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+        };
+        // Always four k-steps: in the last chunk of a K % 64 == 32 layer the weight fragments of k-steps 2, 3 are out-of-range loads (zeros) and the
+        // staged columns past K hold finite prologue values of zeros, so the two extra steps add exact zeros (two code paths here made the
+        // register allocator spill 600 VGPRs).
+        auto compute1 = [&](const BSlot& Bq, int c) { compute_n(Bq, c, std::integral_constant<int, 4>{}); };
+        const bool stamp = a.dbg != nullptr && blockIdx.x == 0 && wave == 0;
+        long long tc_[6] = {0, 0, 0, 0, 0, 0};
+        issue_b(bs[0], a.layer[0], 0);
+        issue_b(bs[1], a.layer[0], 1);
+        issue_b(bs[2], a.layer[0], 2);
+        __syncthreads();                                   // raster zeroed, first constants in place
+        for (int li = 0; li < nl; ++li) {
+            const DenseBlockLayer& L = a.layer[li];
+            const int K = L.K, NC = (K + 63) >> 6;
+            long long v0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+            const float* const sBias = sBias0 + (li & 1) * 160;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+            // ---------------- 1x1: K -> 128 (this wave: 32 of them) over all positions; chunk c lives in ring slot c % 3 and LDS buffer c & 1 ----------------
+            auto step = [&](BSlot& Bq, int c) {
+                long long u0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+                __syncthreads();                           // chunk c staged by the producers
+                if (stamp) { const long long u1 = __builtin_amdgcn_s_memtime(); tc_[0] += u1 - u0; u0 = u1; }
+                compute1(Bq, c);
+                issue_b(Bq, L, c + 3);
+                if (stamp) { const long long u1 = __builtin_amdgcn_s_memtime(); tc_[1] += u1 - u0; }
+            };
+            int c0 = 0;
+            for (; c0 + 3 <= NC; c0 += 3) {
+                step(bs[0], c0);
+                step(bs[1], c0 + 1);
+                step(bs[2], c0 + 2);
+            }
+            if (c0 < NC) step(bs[0], c0);
+            if (c0 + 1 < NC) step(bs[1], c0 + 1);
+            __syncthreads();                               // done with the staging area: the producers put the 3x3 weights there
+            if (stamp) { const long long v1 = __builtin_amdgcn_s_memtime(); tc_[2] += v1 - v0; v0 = v1; }
+            // ---------------- 1x1 epilogue: bias + ReLU -> half -> T raster (pixels only; pad entries stay zero) ----------------
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (i < ntiles) {
+                    float v[16];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 bq = *reinterpret_cast<const f32x4*>(sBias + np * 32 + 8 * g + 4 * hh);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float x = acc[i][4 * g + q] + bq[q];
+                            v[4 * g + q] = (L.flags & 2) ? fmaxf(x, 0.f) : x;
+                        }
+                    }
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        const h4 qa = {_Float16(v[8 * gp + 0]), _Float16(v[8 * gp + 1]), _Float16(v[8 * gp + 2]), _Float16(v[8 * gp + 3])};
+                        const h4 qb = {_Float16(v[8 * gp + 4]), _Float16(v[8 * gp + 5]), _Float16(v[8 * gp + 6]), _Float16(v[8 * gp + 7])};
+                        const u32x2 xa = __builtin_bit_cast(u32x2, qa), xb = __builtin_bit_cast(u32x2, qb);
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(xa[0], xb[0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(xa[1], xb[1], false, false);
+                        if ((vmask >> i) & 1u)
+                            *reinterpret_cast<u32x4*>(sT + (i * 32 + r + PW + 1) * kTPitch + np * 32 + 8 * (2 * gp + hh)) = u32x4{s0[0], s1[0], s0[1], s1[1]};
                     }
                 }
+            }
+            __syncthreads();                               // T complete, 3x3 weights in place
+            if (stamp) { const long long v1 = __builtin_amdgcn_s_memtime(); tc_[3] += v1 - v0; v0 = v1; }
+            {       // next layer's first weight chunks on their way during the 3x3 (same rule as the producers' prefetch)
+                const DenseBlockLayer& Ln = a.layer[li + 1 < nl ? li + 1 : 0];
+                issue_b(bs[0], Ln, 0);
+                issue_b(bs[1], Ln, 1);
+                issue_b(bs[2], Ln, 2);
+            }
+            // ---------------- 3x3: nine shifted GEMMs out of the raster; CFG 0: wave w owns tiles 2w, 2w + 1 (one weight fragment feeds both) ----------------
+            const int t0 = CFG == 0 ? wave * T3 : wave;
+            if (t0 < ntiles && (CFG == 0 || wave < 2)) {
+                f32x16 acc3[T3];
 #pragma unroll
-                for (int gp = 0; gp < 2; ++gp) {
-                    const h4 qa = {_Float16(v[8 * gp + 0]), _Float16(v[8 * gp + 1]), _Float16(v[8 * gp + 2]), _Float16(v[8 * gp + 3])};
-                    const h4 qb = {_Float16(v[8 * gp + 4]), _Float16(v[8 * gp + 5]), _Float16(v[8 * gp + 6]), _Float16(v[8 * gp + 7])};
-                    const u32x2 xa = __builtin_bit_cast(u32x2, qa), xb = __builtin_bit_cast(u32x2, qb);
-                    const auto s0 = __builtin_amdgcn_permlane32_swap(xa[0], xb[0], false, false);
-                    const auto s1 = __builtin_amdgcn_permlane32_swap(xa[1], xb[1], false, false);
-                    if (valid1[i]) *reinterpret_cast<u32x4*>(sT + trow1[i] * kTPitch + nt * 32 + 8 * (2 * gp + hh)) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                for (int j = 0; j < T3; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc3[j][e] = 0.f;
+                const _Float16* const Tb = sT + (t0 * 32 + r) * kTPitch + hh * 8;
+                const _Float16* const Wb = sW3 + lane * 8;
+                // fragments two steps ahead of their MFMAs (rings of three): with one step the LDS latency showed (9.9 k cycles for 4.6 k of MFMAs)
+                h8 af[3][T3], bf[3];
+                auto rd = [&](int tap, int kk, int slot) {
+                    const int shift = (tap / 3) * PW + (tap % 3);
+#pragma unroll
+                    for (int j = 0; j < T3; ++j) af[slot][j] = *reinterpret_cast<const h8*>(Tb + (j * 32 + shift) * kTPitch + kk * 16);
+                    bf[slot] = *reinterpret_cast<const h8*>(Wb + (tap * 8 + kk) * 512);
+                };
+                rd(0, 0, 0);
+                rd(0, 1, 1);
+                for (int tap = 0; tap < 9; ++tap) {
+                    // 24 steps per three taps would keep the ring index static; 8 steps per tap with a ring of 3 does not divide, so the
+                    // slot is carried as 8 * tap mod 3 = (2 * tap) mod 3 through three unrolled variants
+                    const int base = (2 * tap) % 3;
+                    auto body = [&](auto base_c) {
+                        constexpr int BS = decltype(base_c)::value;
+#pragma unroll
+                        for (int kk = 0; kk < 8; ++kk) {
+                            const int nk = kk + 2, ntap = tap + (nk >> 3);
+                            if (ntap < 9) rd(ntap, nk & 7, (BS + kk + 2) % 3);
+#pragma unroll
+                            for (int j = 0; j < T3; ++j)
+                                acc3[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[(BS + kk) % 3], af[(BS + kk) % 3][j], acc3[j], 0, 0, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, T3 + 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, T3, 0);
+                        }
+                    };
+                    if (base == 0) body(std::integral_constant<int, 0>{});
+                    else if (base == 1) body(std::integral_constant<int, 1>{});
+                    else body(std::integral_constant<int, 2>{});
+                }
+#pragma unroll
+                for (int j = 0; j < T3; ++j) {
+                    float v[16];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 bq = *reinterpret_cast<const f32x4*>(sBias + 128 + 8 * g + 4 * hh);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float x = acc3[j][4 * g + q] + bq[q];
+                            v[4 * g + q] = (L.flags & 4) ? fmaxf(x, 0.f) : x;
+                        }
+                    }
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        const h4 qa = {_Float16(v[8 * gp + 0]), _Float16(v[8 * gp + 1]), _Float16(v[8 * gp + 2]), _Float16(v[8 * gp + 3])};
+                        const h4 qb = {_Float16(v[8 * gp + 4]), _Float16(v[8 * gp + 5]), _Float16(v[8 * gp + 6]), _Float16(v[8 * gp + 7])};
+                        const u32x2 xa = __builtin_bit_cast(u32x2, qa), xb = __builtin_bit_cast(u32x2, qb);
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(xa[0], xb[0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(xa[1], xb[1], false, false);
+                        const unsigned off = orow3[j] != kOOB ? orow3[j] + unsigned(L.out_coff + 8 * (2 * gp + hh)) * 2u : kOOB;
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rs_x, off, 0, 0);
+                    }
                 }
             }
-        __syncthreads();                                   // T complete, 3x3 weights landed
-        // ---------------- next layer's first chunk on its way during the 3x3 ----------------
-        if (li + 1 < a.nlayers) {
-            issue_a(a.layer[li + 1], 0);
-            issue_b(a.layer[li + 1], 0, 0);
+            if (stamp) { const long long v1 = __builtin_amdgcn_s_memtime(); tc_[4] += v1 - v0; v0 = v1; }
+            __syncthreads();                               // layer done: T and the 3x3 weights are free, the new channels are visible
+            if (stamp) { const long long v1 = __builtin_amdgcn_s_memtime(); tc_[5] += v1 - v0; }
         }
-        // ---------------- 3x3: nine shifted GEMMs out of the raster, position tile = wave ----------------
-        if (wave < ntiles) {
-            f32x16 acc3;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc3[e] = 0.f;
-            const _Float16* const Tb = sT + (wave * 32 + r) * kTPitch + hh * 8;
-            const _Float16* const Wb = sW3 + lane * 8;
-            h8 af[2], bf[2];
-            auto rd = [&](int st, int slot) {
-                const int tap = st >> 3, kk = st & 7;
-                const int shift = (tap / 3) * PW + (tap % 3);
-                af[slot] = *reinterpret_cast<const h8*>(Tb + shift * kTPitch + kk * 16);
-                bf[slot] = *reinterpret_cast<const h8*>(Wb + st * 512);
-            };
-            rd(0, 0);
-#pragma unroll 8
-            for (int st = 0; st < 72; ++st) {
-                const int cur = st & 1;
-                if (st + 1 < 72) rd(st + 1, cur ^ 1);
-                acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[cur], af[cur], acc3, 0, 0, 0);
-            }
-            float v[16];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 bq = *reinterpret_cast<const f32x4*>(sBias + 128 + 8 * g + 4 * hh);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float x = acc3[4 * g + q] + bq[q];
-                    v[4 * g + q] = (L.flags & 4) ? fmaxf(x, 0.f) : x;
-                }
-            }
-#pragma unroll
-            for (int gp = 0; gp < 2; ++gp) {
-                const h4 qa = {_Float16(v[8 * gp + 0]), _Float16(v[8 * gp + 1]), _Float16(v[8 * gp + 2]), _Float16(v[8 * gp + 3])};
-                const h4 qb = {_Float16(v[8 * gp + 4]), _Float16(v[8 * gp + 5]), _Float16(v[8 * gp + 6]), _Float16(v[8 * gp + 7])};
-                const u32x2 xa = __builtin_bit_cast(u32x2, qa), xb = __builtin_bit_cast(u32x2, qb);
-                const auto s0 = __builtin_amdgcn_permlane32_swap(xa[0], xb[0], false, false);
-                const auto s1 = __builtin_amdgcn_permlane32_swap(xa[1], xb[1], false, false);
-                const unsigned off = valid3 ? orow3 + unsigned(L.out_coff + 8 * (2 * gp + hh)) * 2u : kOOB;
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rs_x, off, 0, 0);
-            }
-        }
-        __syncthreads();                                   // T and the 3x3 weights are free; the new channels are visible to the whole workgroup
+        if (stamp && lane == 0)
+            for (int q = 0; q < 6; ++q) a.dbg[q] = tc_[q];
     }
 }
 
-static size_t block_lds_bytes(int cfg, int H, int W) {
-    const int PW = W + 1, NP = H * PW, M1p = (NP + 31) / 32 * 32, trows = NP + 2 * PW + 2;
-    return size_t(trows) * kTPitch * 2 + 2 * kBBytes + size_t(2) * M1p * kAPitch * 2 + (cfg == 0 ? 0 : kW3Bytes) + 160 * sizeof(float);
+static size_t block_lds_bytes(int H, int W) {
+    const int PW = W + 1, NP = H * PW, trows = NP + 2 * PW + 2;
+    const size_t stage = size_t(kW3Bytes);
+    return size_t(trows) * kTPitch * 2 + stage + 2 * 160 * sizeof(float) + size_t(4) * kMaxK * 2;
 }
 
 static int block_cfg(int H, int W) {
     const int ntiles = (H * (W + 1) + 31) / 32;
-    return ntiles <= 2 ? 1 : (ntiles <= 8 ? 0 : -1);
+    return ntiles <= 2 ? 1 : (ntiles <= 7 ? 0 : -1);
 }
 
 bool DenseBlockEligible(const DenseBlockArgs& a) {
     if (a.x == nullptr || a.wfrag16 == nullptr || a.w16 == nullptr || a.w32 == nullptr) return false;
     if (a.nlayers < 1 || a.nlayers > kMaxBlockLayers || a.n < 1 || a.h < 1 || a.w < 1) return false;
     const int cfg = block_cfg(a.h, a.w);
-    if (cfg < 0 || block_lds_bytes(cfg, a.h, a.w) > size_t(160) * 1024) return false;
-    if (cfg == 0) {        // the 3x3 weights alias the staging area behind the first weight buffer
-        const int M1p = (a.h * (a.w + 1) + 31) / 32 * 32;
-        if (size_t(kBBytes) + size_t(2) * M1p * kAPitch * 2 < size_t(kW3Bytes)) return false;
-    }
+    if (cfg < 0 || block_lds_bytes(a.h, a.w) > size_t(160) * 1024) return false;
     if ((a.pitch & 7) || (a.in_coff & 7) || (reinterpret_cast<uintptr_t>(a.x) & 15) || (reinterpret_cast<uintptr_t>(a.wfrag16) & 15) ||
         (reinterpret_cast<uintptr_t>(a.w16) & 15))
         return false;
-    if (int64_t(a.h) * a.w * a.pitch * 2 >= (int64_t(1) << 31)) return false;
+    if (int64_t(a.h) * a.w * a.pitch * 2 >= (int64_t(1) << 31) || a.w16_bytes == 0 || a.w16_bytes >= (uint64_t(1) << 31)) return false;
     for (int l = 0; l < a.nlayers; ++l) {
         const DenseBlockLayer& L = a.layer[l];
-        if (L.K < 64 || (L.K & 31) || a.in_coff + L.K > a.pitch) return false;
+        if (L.K < 64 || (L.K & 31) || L.K > kMaxK || a.in_coff + L.K > a.pitch) return false;
         if ((L.out_coff & 7) || L.out_coff + 32 > a.pitch) return false;
         if (L.out_coff < a.in_coff + L.K && L.out_coff + 32 > a.in_coff) return false;          // the new channels must not overlap what the layer reads
+        if (uint64_t(L.w1) + uint64_t(128) * L.K > a.w16_bytes / 2 || uint64_t(L.w3) + 32 * 1152 > a.w16_bytes / 2) return false;
         if ((L.w1 & 7) || (L.w3 & 7)) return false;
         if (L.ps != 0xffffffffu && ((L.ps & 7) || (L.pt & 7) || L.pt == 0xffffffffu)) return false;
-        // the first chunk of a layer is requested while the previous layer's 3x3 is still running: it must not contain that layer's output
-        if (l > 0 && a.layer[l - 1].out_coff < a.in_coff + 64 && a.layer[l - 1].out_coff + 32 > a.in_coff) return false;
+        // the first three chunks of a layer are requested while the previous layer's 3x3 is still running: they must not contain that layer's output
+        if (l > 0 && a.layer[l - 1].out_coff < a.in_coff + 192 && a.layer[l - 1].out_coff + 32 > a.in_coff) return false;
     }
     return true;
 }
@@ -307,7 +456,7 @@ bool DenseBlockEligible(const DenseBlockArgs& a) {
 hipError_t LaunchDenseBlockF16(const DenseBlockArgs& a, hipStream_t stream) {
     if (!DenseBlockEligible(a)) return hipErrorInvalidValue;
     const int cfg = block_cfg(a.h, a.w);
-    const size_t lds = block_lds_bytes(cfg, a.h, a.w);
+    const size_t lds = block_lds_bytes(a.h, a.w);
     if (cfg == 0) dense_block_f16_kernel<0><<<dim3(a.n), dim3(512), lds, stream>>>(a);
     else dense_block_f16_kernel<1><<<dim3(a.n), dim3(512), lds, stream>>>(a);
     return hipGetLastError();

@@ -1235,7 +1235,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
             if (s3.out.c_off < s1.in.c_off + s1.in.c && s3.out.c_off + 32 > s1.in.c_off) return false;
             if ((s1.pre_scale_off >= 0) != (s1.pre_shift_off >= 0)) return false;
             const int64_t ntiles = (s1.in.h * (s1.in.w + 1) + 31) / 32;
-            if (ntiles > 8) return false;
+            if (ntiles > 7) return false;
             // T must have no other reader: the fused kernel never writes it to memory
             for (size_t j = i + 2; j < plan.steps.size(); ++j) {
                 const Step& q = plan.steps[j];
@@ -1253,8 +1253,8 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                     const Step& f1 = plan.steps[i], &c1 = plan.steps[i + 2 * n], &p3 = plan.steps[i + 2 * n - 1];
                     if (c1.in.buf != f1.in.buf || c1.in.pitch != f1.in.pitch || c1.in.c_off != f1.in.c_off || c1.in.n != f1.in.n || c1.in.h != f1.in.h || c1.in.w != f1.in.w)
                         break;
-                    // a layer's first 64 input channels are requested while the previous layer's 3x3 still runs: they must not be its output
-                    if (p3.out.c_off < c1.in.c_off + 64 && p3.out.c_off + 32 > c1.in.c_off) break;
+                    // a layer's first 192 input channels are requested while the previous layer's 3x3 still runs: they must not be its output
+                    if (p3.out.c_off < c1.in.c_off + 192 && p3.out.c_off + 32 > c1.in.c_off) break;
                 }
                 ++n;
             }

@@ -50,7 +50,7 @@ int main(int argc, char** argv) {
     }
     _Float16 *dx, *dw16, *dwf;
     float* dw32;
-    CK(hipMalloc(&dx, x.size() * 2)); CK(hipMalloc(&dw16, w16.size() * 2)); CK(hipMalloc(&dwf, w16.size() * 2)); CK(hipMalloc(&dw32, w32.size() * 4));
+    CK(hipMalloc(&dx, x.size() * 2)); CK(hipMalloc(&dw16, w16.size() * 2)); CK(hipMalloc(&dwf, w16.size() * 2)); CK(hipMalloc(&dw32, std::max(w32.size() * 4, w16.size() * 4)));
     CK(hipMemcpy(dx, x.data(), x.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(dw16, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(dw32, w32.data(), w32.size() * 4, hipMemcpyHostToDevice));
@@ -59,7 +59,7 @@ int main(int argc, char** argv) {
         CK(ie::LaunchPermuteWeightsFrag16(dw16 + a.layer[l].w1, dwf + a.layer[l].w1, 128, a.layer[l].K, nullptr));
         CK(ie::LaunchPermuteWeightsFrag16(dw16 + a.layer[l].w3, dwf + a.layer[l].w3, 32, 1152, nullptr));
     }
-    a.x = dx; a.w16 = dw16; a.wfrag16 = dwf; a.w32 = dw32;
+    a.x = dx; a.w16 = dw16; a.wfrag16 = dwf; a.w32 = dw32; a.w16_bytes = w16.size() * 2;
     CK(ie::InitKernelsBlock());
     if (!ie::DenseBlockEligible(a)) { printf("not eligible\n"); return 2; }
     CK(ie::LaunchDenseBlockF16(a, nullptr));
@@ -125,6 +125,21 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
+    {
+        long long* dbg;
+        CK(hipMalloc(&dbg, 128));
+        CK(hipMemset(dbg, 0, 128));
+        a.dbg = dbg;
+        CK(ie::LaunchDenseBlockF16(a, nullptr));
+        CK(hipDeviceSynchronize());
+        long long h[16];
+        CK(hipMemcpy(h, dbg, 128, hipMemcpyDeviceToHost));
+        printf("  consumer wave 0, cycles per layer: 1x1 loop total %.0f (of it barrier waits %.0f, compute + issue %.0f), 1x1 epilogue -> barrier %.0f, 3x3 + stores %.0f, closing barrier %.0f\n",
+               double(h[2]) / NL, double(h[0]) / NL, double(h[1]) / NL, double(h[3]) / NL, double(h[4]) / NL, double(h[5]) / NL);
+        printf("  producer wave 4, cycles per layer: 1x1 loop total %.0f (commit %.0f, issue %.0f, barrier waits %.0f), 3x3 weights -> LDS -> barrier %.0f, prefetch -> closing barrier %.0f\n",
+               double(h[11]) / NL, double(h[8]) / NL, double(h[9]) / NL, double(h[10]) / NL, double(h[12]) / NL, double(h[13]) / NL);
+        a.dbg = nullptr;
+    }
     double flops = 0;
     for (int l = 0; l < NL; ++l) flops += 2.0 * B * H * W * (128.0 * a.layer[l].K + 32.0 * 1152);
     printf("  %.1f us per launch (%.2f us per layer), %.1f TFLOP/s\n", ms * 100.f, ms * 100.f / NL, flops / (ms * 1e-4) / 1e12);

@@ -865,6 +865,41 @@ def test_fp16_random_conv_graphs_vs_oracle(tmp_path, seed):
     print(f"fp16 seed {seed}: worst rel err {worst:.2e}")
 
 
+@pytest.mark.parametrize("batch,image,stem,blocks", [(3, 56, 128, (4, 3)), (5, 56, 256, (2, 5)), (2, 28, 192, (6,)), (9, 112, 192, (2, 4, 3))])
+def test_fp16_dense_block_chain_kernel(tmp_path, batch, image, stem, blocks):
+    """dense_block_f16_kernel (kernels_block.hip): chains of dense layers (BN-ReLU-1x1 to 128, BN-ReLU-3x3 to 32) on 14x14 / 7x7 maps run as ONE
+    launch per chain, one workgroup per image, the bottleneck tensor never leaving LDS.  DenseNet-shaped graphs whose blocks start at K0 =
+    128 ... 256 channels (odd and even chunk counts, K % 64 == 32 tails, 7- and 2-tile maps, ragged chains cut where a layer would read what
+    its predecessor writes too early): against the float64 oracle within F16_RTOL, and against the same plan run layer by layer."""
+    mb = models.densenet(batch, growth=32, blocks=blocks, stem=stem, image=image, classes=24, seed=91)
+    path = models.write_repo(str(tmp_path), "dblock", mb)
+    x = models.synthetic_input((batch, 3, image, image), stream="dblock")
+    ref = O.run(O.load_model(mb), {"data_0": x}, dtype=np.float64)["fc6_1"].reshape(batch, 24)
+
+    def go():
+        m = B.CreateModel(path, "dblock")
+        try:
+            y = infer(m, "", "data_0", x, "fc6_1", [batch, 24, 1, 1])[0].reshape(batch, 24).copy()
+            din, _ = B.Prepare(m, [[batch, 3, image, image]], 1)
+            B.CopyToDevice(m, din[0], x)
+            B.RunPrepared(m, 1, True)
+            return y, [p_["kernel"] for p_ in B.Profile(m, 1)], B.DescribeModel(path, batch)["plan"]
+        finally:
+            m.Destroy()
+    y, kern, plan = _run_with_env(_f16_env(IE_AUTOTUNE="0"), go)
+    y0, kern0, plan0 = _run_with_env(_f16_env(IE_AUTOTUNE="0", IE_NO_DENSE_BLOCK="1"), go)
+    chains = [s for s in plan["steps"] if s.get("algo") == "dense_block"]
+    assert chains and not [s for s in plan0["steps"] if s.get("algo") == "dense_block"]
+    assert all(len(s["parts"]) % 2 == 0 and s["parts"][0]["k"] == [1, 1] and s["parts"][1]["k"] == [3, 3] for s in chains)
+    nk = [k for k in kern if k.startswith("dense_block_f16_kernel")]
+    assert len(nk) == len(chains) and not any(k.startswith("dense_block") for k in kern0), kern
+    layers = sum(len(s["parts"]) // 2 for s in chains)
+    e, e0, d = rel_err(y, ref), rel_err(y0, ref), rel_err(y, y0)
+    print(f"dense-block chains B={batch} image={image} stem={stem} blocks={blocks}: {len(chains)} chains / {layers} layers "
+          f"({[len(s['parts']) // 2 for s in chains]}), rel err {e:.2e} (layer by layer {e0:.2e}, between the two {d:.2e})")
+    assert e < F16_RTOL and e0 < F16_RTOL and d < F16_RTOL
+
+
 def test_fp16_densenet121_fixture_and_batch_independence(densenet_repo, tmp_path):
     """DenseNet-121 in fp16 mode selected through config.json ("precision": "fp16"), B=2 against the float64 fixture and the
     B=32 size-independent property (each image's logits equal that image run alone, up to summation-order rounding)."""
