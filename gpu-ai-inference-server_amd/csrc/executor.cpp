@@ -94,7 +94,7 @@ namespace {
 std::string tune_file_header() {
     std::ostringstream o;
     o << kTuneFileTag << ' ' << kNumIgemmTiles << ' ' << kNumConvRasterTiles << ' ' << kNumConvWs32Tiles << ' ' << kNumConvWs3Tiles << ' '
-      << kNumConvDirectTiles << ' ' << kNumConvWinoTiles << ' ' << kNumConvX6Tiles;
+      << kNumConvDirectTiles << ' ' << kNumConvWinoTiles << ' ' << kNumConvX6Tiles << ' ' << kNumConvWs8Tiles;
     return o.str();
 }
 
@@ -144,6 +144,7 @@ DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id, 
         if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsWino();
         if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsX6();
         if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsBlock();
+        if (g_kernels_err == hipSuccess) g_kernels_err = InitKernelsWs8();
     });
     check(g_kernels_err, "InitKernels");
     fp32_split_ = opt.fp32_split && opt.precision == Precision::F32;
@@ -258,11 +259,15 @@ void DeviceModel::BuildInstance(PlanInstance& pi, const std::vector<std::vector<
                     check(hipMemset(w_->d_weights8, 0, std::max<size_t>(w_->weight_floats, 16)), "hipMemset(weights8)");
                     w_->device_bytes += w_->weight_floats;
                     int64_t aux = 0;
+                    auto add8 = [&](const Step& st, int i) {
+                        if (st.kind != StepKind::Conv || st.algo != ConvAlgo::IgemmF8) return;
+                        w_->f8_convs.push_back({i, st.w_off, int(st.out.c), int(st.kh * st.kw * st.in.c), st.in_src, aux});
+                        aux += 2 * ((st.out.c + 3) / 4 * 4);
+                    };
                     for (size_t i = 0; i < pi.plan.steps.size(); ++i) {
                         const Step& st = pi.plan.steps[i];
-                        if (st.kind != StepKind::Conv || st.algo != ConvAlgo::IgemmF8) continue;
-                        w_->f8_convs.push_back({int(i), st.w_off, int(st.out.c), int(st.kh * st.kw * st.in.c), st.in_src, aux});
-                        aux += 2 * ((st.out.c + 3) / 4 * 4);
+                        if (st.parts.empty()) add8(st, int(i));
+                        else for (const Step& q : st.parts) add8(q, int(i));       // a projection-shortcut step: both of its convs
                     }
                     check(hipMalloc(reinterpret_cast<void**>(&w_->d_f8_aux), size_t(std::max<int64_t>(aux, 4)) * sizeof(float)), "hipMalloc(f8 aux)");
                     w_->f8_aux_floats = size_t(aux);
@@ -568,7 +573,7 @@ void DeviceModel::PrepareF8(const std::vector<float>* adopt) {
         shapes.push_back(sh);
     }
     PlanInstance cal;
-    cal.plan = BuildPlan(*model_, shapes, Precision::F16);
+    cal.plan = BuildPlan(*model_, shapes, Precision::F16, true);       // the fp8 plan's step fusions, so the step lists line up
     if (cal.plan.steps.size() != W.act_scale.size()) throw std::runtime_error("fp8 calibration: the fp16 plan of the graph has a different step list");
     std::vector<float>().swap(cal.plan.weights);
     float* d_amax = nullptr;
@@ -770,6 +775,43 @@ void DeviceModel::Autotune(PlanInstance& pi, size_t nsteps, bool allow_search) {
         for (size_t si = 0; si < nsteps && si < pi.plan.steps.size(); ++si) {
             Step& s = pi.plan.steps[si];
             if (s.kind != StepKind::Conv || s.algo == ConvAlgo::Naive || s.algo == ConvAlgo::Stem) continue;
+            if (s.algo == ConvAlgo::DualF8) {
+                if (!s.in.f8) continue;                // (a calibration plan: never tuned)
+                std::vector<int64_t> keyd = {s.out.n * s.out.h * s.out.w, s.out.c, s.in.c, s.parts.size() == 2 ? s.parts[0].in.c : 0, s.parts.size() == 2 ? s.parts[0].sh : 0,
+                                             s.in.pitch, s.out.pitch, int64_t(ConvAlgo::DualF8), s.bias_off >= 0};
+                {
+                    std::lock_guard<std::mutex> g(w_->tune_mu);
+                    auto hit = w_->tune_cache.find(keyd);
+                    if (hit != w_->tune_cache.end()) { s.tile = hit->second.first; continue; }
+                }
+                if (!allow_search || !w_->f8_ready) continue;
+                searched = true;
+                float bestd = 1e30f;
+                int best_t = 101;
+                for (int t = 1; t < kNumConvWs8Tiles; ++t) {
+                    Step trial = s;
+                    trial.tile = 100 + t;
+                    if (!ConvWs8Eligible(MakeConvArgs(pi, trial), t)) continue;
+                    LaunchStep(pi, trial, stream_);
+                    float ms_best = 1e30f;
+                    for (int rep = 0; rep < 3; ++rep) {
+                        if (scrub) check(hipMemsetAsync(scrub, 0, kScrubBytes, stream_), "hipMemsetAsync(scrub)");
+                        check(hipEventRecord(e0, stream_), "hipEventRecord");
+                        LaunchStep(pi, trial, stream_);
+                        check(hipEventRecord(e1, stream_), "hipEventRecord");
+                        check(hipEventSynchronize(e1), "hipEventSynchronize");
+                        float ms = 0;
+                        check(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime");
+                        ms_best = std::min(ms_best, ms);
+                    }
+                    if (ms_best < bestd) { bestd = ms_best; best_t = 100 + t; }
+                }
+                s.tile = best_t;
+                std::lock_guard<std::mutex> g(w_->tune_mu);
+                w_->tune_cache[keyd] = {best_t, 1};
+                w_->tune_dirty = true;
+                continue;
+            }
             if (s.algo == ConvAlgo::DenseBlock) {
                 // the parts get their own kernel choices (what runs when the chain kernel declines, and the yardstick); chain vs parts is
                 // one more timed choice (tile 1 = one launch, 0 = the 2n plain launches)
@@ -906,10 +948,13 @@ void DeviceModel::Autotune(PlanInstance& pi, size_t nsteps, bool allow_search) {
                 searched = true;
                 float best8 = 1e30f;
                 int best_t = s.tile;
-                for (int t = 0; t < kNumConvF8Tiles; ++t) {
-                    if (kIgemmTiles[t].bn > 32 && N <= 32) continue;
+                for (int tc = 0; tc < kNumConvF8Tiles + kNumConvWs8Tiles; ++tc) {
+                    // candidates: the tiled implicit GEMM's tiles, then (tile >= 100) the weights-stationary 1x1 kernel's
+                    const int t = tc < kNumConvF8Tiles ? tc : 100 + (tc - kNumConvF8Tiles);
+                    if (t < 100 && kIgemmTiles[t].bn > 32 && N <= 32) continue;
                     Step trial = s;
                     trial.tile = t;
+                    if (t >= 100 && !ConvWs8Eligible(MakeConvArgs(pi, trial), t - 100)) continue;
                     LaunchStep(pi, trial, stream_);
                     float ms_best = 1e30f;
                     for (int rep = 0; rep < 3; ++rep) {
@@ -1265,6 +1310,17 @@ ConvArgs DeviceModel::MakeConvArgs(const PlanInstance& pi, const Step& s) const 
                 a.w8 = static_cast<const char*>(W.d_weights8) + fc.w_off;
                 a.escale = W.d_f8_aux + fc.aux_off + (fc.cout + 3) / 4 * 4;
             }
+        if (s.algo == ConvAlgo::DualF8 && s.parts.size() == 2) {       // the projection conv rides along as a second GEMM
+            const Step& pj = s.parts[0];
+            a.in2 = make_arg(pi, pj.in);
+            a.sh2 = pj.sh; a.sw2 = pj.sw;
+            a.bias_b = wp(pj.bias_off);
+            for (const auto& fc : W.f8_convs)
+                if (fc.w_off == pj.w_off) {
+                    a.w8b = static_cast<const char*>(W.d_weights8) + fc.w_off;
+                    a.escale_b = W.d_f8_aux + fc.aux_off + (fc.cout + 3) / 4 * 4;
+                }
+        }
     }
     return a;
 }
@@ -1275,6 +1331,18 @@ void DeviceModel::LaunchStep(const PlanInstance& pi, const Step& s_in, hipStream
     auto wp = [&](int64_t off) -> const float* { return off >= 0 ? wb + off : nullptr; };
     switch (s.kind) {
         case StepKind::Conv: {
+            if (s.algo == ConvAlgo::DualF8) {
+                if (s.in.f8) {          // fp8 plan: the two GEMMs of one launch; e4m3 tensors never reach another kernel
+                    if (!w_->f8_ready) throw std::runtime_error("fp8 precision: scales are not calibrated yet");
+                    const ConvArgs a = MakeConvArgs(pi, s);
+                    const int t = s.tile >= 100 ? s.tile - 100 : 1;
+                    if (a.in2.p == nullptr || !ConvWs8Eligible(a, t)) throw std::runtime_error("fp8 precision: the projection-shortcut step " + s.name + " cannot run on the dual 1x1 kernel");
+                    check(LaunchConvWs1x1F8(a, t, stream_), "conv1x1_ws_f8(dual)");
+                } else {                // the fp16 plan of the fp8 calibration: the same step list, the two plain convs
+                    for (const Step& q : s.parts) LaunchStep(pi, q, stream_);
+                }
+                break;
+            }
             if (s.algo == ConvAlgo::DenseBlock) {
                 DenseBlockArgs b;
                 if (s.tile != 0 && MakeBlockArgs(pi, s, &b) && DenseBlockEligible(b)) check(LaunchDenseBlockF16(b, stream_), "dense_block_f16");
@@ -1328,7 +1396,8 @@ void DeviceModel::LaunchStep(const PlanInstance& pi, const Step& s_in, hipStream
                 // e4m3 tensors: only the fp8 kernel may touch them; a declined launch is an error, never a hand-over to a kernel that
                 // would read the bytes as floats
                 if (!w_->f8_ready) throw std::runtime_error("fp8 precision: scales are not calibrated yet");
-                check(LaunchConvIgemmF8(a, s_in.tile, stream_), "conv_igemm_f8");
+                if (s_in.tile >= 100) check(LaunchConvWs1x1F8(a, s_in.tile - 100, stream_), "conv1x1_ws_f8");        // weights-stationary 1x1 (kernels_ws8.hip)
+                else check(LaunchConvIgemmF8(a, s_in.tile, stream_), "conv_igemm_f8");
                 break;
             }
             if (a.in.f8 || a.res.f8 || (a.out.f8 && s_in.algo != ConvAlgo::Stem)) throw std::runtime_error("internal error: fp8 tensor reached a non-fp8 conv kernel");
@@ -1410,6 +1479,8 @@ static std::string kernel_label(const Step& s) {
             if (s.algo == ConvAlgo::Naive) return "conv_naive_kernel";
             if (s.algo == ConvAlgo::DenseBlock) return s.tile != 0 ? "dense_block_f16_kernel<" + std::to_string(s.parts.size() / 2) + " layers>" : "dense_block_parts<" + std::to_string(s.parts.size()) + " launches>";
             if (s.algo == ConvAlgo::DenseFused) return (s.tile >= 4 ? "conv_dense_fused_ws_kernel<t" : "conv_dense_fused_kernel<t") + std::to_string(s.tile) + ">";
+            if (s.algo == ConvAlgo::DualF8) return s.in.f8 ? "conv1x1_ws_f8_kernel<dual,t" + std::to_string(s.tile >= 100 ? s.tile - 100 : 1) + ">" : "dual_f8_parts<2 launches>";
+            if (s.algo == ConvAlgo::IgemmF8 && s.tile >= 100) return "conv1x1_ws_f8_kernel<t" + std::to_string(s.tile - 100) + ">";
             if (s.algo == ConvAlgo::IgemmF8)
                 return "conv_igemm_f8_kernel<" + std::to_string(kIgemmTiles[s.tile].bm) + "x" + std::to_string(kIgemmTiles[s.tile].bn) + ">";
             if (s.algo == ConvAlgo::Direct) {       // one launcher family, three kernels (kernels_direct.hip): report the one that runs

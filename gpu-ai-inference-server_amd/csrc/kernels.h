@@ -41,6 +41,14 @@ struct ConvArgs {
     const void* w8 = nullptr;
     const float* escale = nullptr;
     float res_scale = 1.f, out_qscale = 1.f;
+    // fp8 mode, DUAL 1x1 (kernels_ws8.hip): a second GEMM accumulated into the same output -- the projection shortcut of a bottleneck block,
+    // out = act(conv(in) + conv_b(in2)) with in2 read at pixel (oy * sh2, ox * sw2); in2.p == null: none
+    TensorArg in2;
+    const void* w8b = nullptr;
+    const float* escale_b = nullptr;
+    const float* bias_b = nullptr;
+    int sh2 = 1, sw2 = 1;
+    int64_t in2_bytes = 0;
     int debug = 0;                     // timing-only ablation bits (IE_DEBUG_ABLATE), 0 in production
     int64_t in_bytes = 0;              // filled by LaunchConvIgemm: byte span of the input view (buffer descriptor range)
 };
@@ -175,6 +183,12 @@ constexpr int kNumConvF8Tiles = 7;
 bool ConvF8Eligible(const ConvArgs& a, int tile);
 hipError_t LaunchConvIgemmF8(const ConvArgs& a, int tile, hipStream_t stream);
 hipError_t InitKernelsF8();
+// fp8 weights-stationary 1x1 conv (kernels_ws8.hip): weights + epilogue constants in LDS, activations streamed from HBM into MFMA fragments;
+// with a.in2 set also the projection shortcut's GEMM in the same launch.  tile: {N tiles of 32 per workgroup, waves} = {8,8} {4,8} {2,8} {4,4} {2,4}
+constexpr int kNumConvWs8Tiles = 5;
+bool ConvWs8Eligible(const ConvArgs& a, int tile);
+hipError_t LaunchConvWs1x1F8(const ConvArgs& a, int tile, hipStream_t stream);
+hipError_t InitKernelsWs8();
 // w8[o, :] = e4m3(w[o, :] / wscale[o]) with wscale[o] = max|w[o, :]| / 448, one workgroup per row
 hipError_t LaunchQuantizeRowsE4m3(const float* w, void* w8, float* wscale, int rows, int K, hipStream_t stream);
 hipError_t LaunchScaleVector(const float* src, float* dst, float s, int n, hipStream_t stream);

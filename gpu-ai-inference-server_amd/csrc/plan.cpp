@@ -210,7 +210,7 @@ ModelInfo DescribeModel(const OnnxModel& m) {
     return info;
 }
 
-Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& input_shapes, Precision precision) {
+Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& input_shapes, Precision precision, bool f8_fusions) {
     Lowering L(m);
     Plan plan;
     plan.precision = precision;
@@ -1293,6 +1293,67 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
         }
     }
 
+    // ---- projection shortcuts (fp8): conv3 + residual where the residual is a 1x1 projection conv -> ONE step of two GEMMs ------------------------
+    // Pattern: step j = 1x1/s1 conv C with a fused residual whose producer is step i < j = a plain 1x1 conv P (any stride, no prologue, no
+    // residual, no ReLU) read by nothing else.  out = relu(C(a) + P(x)) then runs as two accumulator sets of one launch (kernels_ws8.hip) and
+    // P's output -- the largest tensor of the block -- is never written.  P moves down to C's position (everything between them is independent
+    // of P's output: its only reader is C).
+    if ((precision == Precision::F8 || f8_fusions) && !std::getenv("IE_NO_DUAL_F8")) {
+        for (size_t j = 0; j < plan.steps.size(); ++j) {
+            Step& c = plan.steps[j];
+            if (c.kind != StepKind::Conv || !c.has_in2 || !c.parts.empty() || c.kh != 1 || c.kw != 1 || c.sh != 1 || c.sw != 1 || c.pt || c.pl || c.pb || c.pr) continue;
+            if (c.pre_scale_off >= 0 || c.in.nchw || c.out.nchw || c.in.c % 32 || c.out.c % 32 || c.in2_src < 0 || size_t(c.in2_src) >= j) continue;
+            const size_t i = size_t(c.in2_src);
+            const Step& pr = plan.steps[i];
+            if (pr.kind != StepKind::Conv || !pr.parts.empty() || pr.has_in2 || pr.relu || pr.pre_scale_off >= 0 || pr.kh != 1 || pr.kw != 1 || pr.pt || pr.pl || pr.pb || pr.pr) continue;
+            if (pr.in.nchw || pr.in.c % 32 || pr.out.buf != c.in2.buf || pr.out.c_off != c.in2.c_off || pr.out.c != c.in2.c || pr.out.pitch != c.in2.pitch) continue;
+            if (pr.out.n != c.out.n || pr.out.h != c.out.h || pr.out.w != c.out.w || pr.out.c != c.out.c) continue;
+            if (precision == Precision::F8 && (!pr.in.f8 || !c.in.f8 || !c.out.f8)) continue;
+            if (pr.in.buf == c.out.buf || pr.out.buf == c.out.buf) continue;
+            // P's output must have no other reader, and P's INPUT must still hold its value at C's position (not recycled in between)
+            bool ok = true;
+            for (size_t q = i + 1; q < plan.steps.size() && ok; ++q) {
+                const Step& t = plan.steps[q];
+                if (q != j && (t.in.buf == pr.out.buf || (t.has_in2 && t.in2.buf == pr.out.buf))) ok = false;
+                if (q > j && t.out.buf == pr.out.buf) break;
+            }
+            for (size_t q = i + 1; q < j && ok; ++q)
+                if (plan.steps[q].out.buf == pr.in.buf) ok = false;
+            for (size_t o = 0; o < out_vals.size() && ok; ++o) if (view_of(out_vals[o]).buf == pr.out.buf) ok = false;
+            if (!ok) continue;
+            Step f = c;
+            f.algo = ConvAlgo::DualF8;
+            f.tile = 1;
+            f.splitk = 1;
+            f.has_in2 = false;
+            f.in2 = View();
+            f.in2_src = -1;
+            f.name = pr.name + " (+) " + c.name;
+            f.flops = pr.flops + c.flops;
+            f.bytes = pr.bytes + c.bytes;
+            f.parts = {pr, c};
+            // steps i+1 .. j-1 move up by one, the fused step takes position j - 1 ... simpler: erase i, replace j (indices above i shift by -1)
+            std::vector<Step> ns;
+            ns.reserve(plan.steps.size() - 1);
+            for (size_t q = 0; q < plan.steps.size(); ++q) {
+                if (q == i) continue;
+                ns.push_back(q == j ? f : plan.steps[q]);
+            }
+            auto remap = [&](int src) { return src < 0 ? src : (size_t(src) == i ? int(j) - 1 : (size_t(src) > i ? src - 1 : src)); };
+            for (size_t q = 0; q < ns.size(); ++q) {
+                Step& st = ns[q];
+                st.idx = int(q);
+                st.in_src = remap(st.in_src);
+                st.in2_src = remap(st.in2_src);
+                for (Step& part : st.parts) { part.in_src = remap(part.in_src); part.in2_src = remap(part.in2_src); }
+            }
+            // inside the fused step: the last conv's shortcut comes from the projection part (no plan step of its own any more)
+            ns[j - 1].parts[1].in2_src = -1;
+            plan.steps = std::move(ns);
+            --j;
+        }
+    }
+
     // ---- I/O descriptors ---------------------------------------------------------------------------
     for (size_t i = 0; i < m.inputs.size(); ++i) {
         IoDesc d;
@@ -1336,7 +1397,7 @@ static std::string json_escape(const std::string& s) {
 
 std::string PlanToJson(const Plan& p) {
     static const char* kinds[] = {"conv", "pool", "gap", "eltwise", "copy"};
-    static const char* algos[] = {"igemm_vec", "igemm_scalar", "naive", "raster3x3", "ws1x1", "ws3x3", "stem", "direct", "igemm_f8", "dense_fused", "wino3x3", "conv1x1_x6", "dense_block"};
+    static const char* algos[] = {"igemm_vec", "igemm_scalar", "naive", "raster3x3", "ws1x1", "ws3x3", "stem", "direct", "igemm_f8", "dense_fused", "wino3x3", "conv1x1_x6", "dense_block", "dual_f8"};
     std::ostringstream o;
     o.precision(17);
     o << "{\"inputs\":[";

@@ -54,8 +54,11 @@ enum class ConvAlgo : int {
     DenseFused = 9,   // fp32: 3x3 growth conv of dense layer L + 1x1 bottleneck conv of layer L+1 in one launch (Step::parts holds the two convs)
     Wino3x3 = 10,     // fp32: Winograd F(2x2, 3x3) for 3x3/s1/p1 convs with 32 output channels on even-sized images (2.25x fewer MACs)
     X6 = 11,          // fp32 1x1 conv on the bf16 matrix pipe with exactly split operands (kernels_x6.hip; opt-in IE_FP32_SPLIT=1)
-    DenseBlock = 12   // fp16: a chain of dense layers (1x1 K -> 128, 3x3 128 -> 32) in ONE launch, one workgroup per image, the bottleneck tensor
+    DenseBlock = 12,  // fp16: a chain of dense layers (1x1 K -> 128, 3x3 128 -> 32) in ONE launch, one workgroup per image, the bottleneck tensor
                       // kept in LDS (kernels_block.hip).  Step::parts = the 2n conv steps as the planner emitted them; tile 1 = fused, 0 = the parts
+    DualF8 = 13       // fp8: a bottleneck block's last 1x1 conv AND the projection conv of its shortcut as two GEMMs of one launch (kernels_ws8.hip):
+                      // the shortcut tensor never exists.  Step::parts = {projection conv, last conv}; this step's own fields repeat the last
+                      // conv's with has_in2 cleared.  The fp16 plan built for the fp8 calibration carries the same step and runs its parts.
 };
 
 struct Step {
@@ -122,7 +125,9 @@ ModelInfo DescribeModel(const OnnxModel& m);
 
 // Build the plan for concrete input shapes (one entry per graph input, in graph order).
 // Throws std::runtime_error with an ORT-like message on unsupported ops or shape mismatches.
-Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& input_shapes, Precision precision = Precision::F32);
+// f8_fusions: apply the step fusions of the fp8 mode (DualF8) whatever the precision -- the fp8 calibration runs the graph in fp16 and needs
+// the SAME step list as the fp8 plan it calibrates.
+Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& input_shapes, Precision precision = Precision::F32, bool f8_fusions = false);
 
 std::string PlanToJson(const Plan& p);
 

@@ -89,8 +89,16 @@ def run_plan(plan: dict, blob: np.ndarray, feeds: dict, act_scales=None, fp8: bo
         else:
             _view(bufs, v, n)[...] = x.reshape(n, v["c"], v["h"] * v["w"])[:, None, :, :].transpose(0, 1, 3, 2).reshape(n, v["h"], v["w"], v["c"])
     steps = []
-    for s in plan["steps"]:          # a fused dense-layer step carries the two convs it replaces: execute those
-        steps.extend(s["parts"] if s.get("parts") else [s])
+    for s in plan["steps"]:          # a fused step carries the convs it replaces: execute those
+        if s.get("parts") and s.get("algo") == "dual_f8":
+            # projection shortcut + last conv of a bottleneck block as two GEMMs of one launch: the shortcut is added in fp32, never
+            # quantised; the result takes the FUSED step's scale
+            pj, cv = dict(s["parts"][0]), dict(s["parts"][1])
+            pj["_exact_out"] = True
+            cv["idx"] = s["idx"]
+            steps.extend([pj, cv])
+        else:
+            steps.extend(s["parts"] if s.get("parts") else [s])
     for s in steps:
         vin, vout = s["in"], s["out"]
         xin = _view(bufs, vin, n)
@@ -160,7 +168,7 @@ def run_plan(plan: dict, blob: np.ndarray, feeds: dict, act_scales=None, fp8: bo
             y = xin
         else:
             raise NotImplementedError(s["kind"])
-        if fp8 and vout["f8"]:
+        if fp8 and vout["f8"] and not s.get("_exact_out"):
             y = quantize(y, act_scales[s["idx"]])
         elif fp8 and vout["f16"]:
             y = y.astype(np.float16).astype(np.float64)
