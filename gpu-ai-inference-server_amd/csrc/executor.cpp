@@ -94,7 +94,7 @@ namespace {
 std::string tune_file_header() {
     std::ostringstream o;
     o << kTuneFileTag << ' ' << kNumIgemmTiles << ' ' << kNumConvRasterTiles << ' ' << kNumConvWs32Tiles << ' ' << kNumConvWs3Tiles << ' '
-      << kNumConvDirectTiles << ' ' << kNumConvWinoTiles << ' ' << kNumConvX6Tiles << ' ' << kNumConvWs8Tiles;
+      << kNumConvDirectTiles << ' ' << kNumConvWinoTiles << ' ' << kNumConvX6Tiles << ' ' << kNumConvWs8Tiles << ' ' << kNumConvWs38Tiles;
     return o.str();
 }
 
@@ -948,13 +948,13 @@ void DeviceModel::Autotune(PlanInstance& pi, size_t nsteps, bool allow_search) {
                 searched = true;
                 float best8 = 1e30f;
                 int best_t = s.tile;
-                for (int tc = 0; tc < kNumConvF8Tiles + kNumConvWs8Tiles; ++tc) {
-                    // candidates: the tiled implicit GEMM's tiles, then (tile >= 100) the weights-stationary 1x1 kernel's
-                    const int t = tc < kNumConvF8Tiles ? tc : 100 + (tc - kNumConvF8Tiles);
+                for (int tc = 0; tc < kNumConvF8Tiles + kNumConvWs8Tiles + kNumConvWs38Tiles; ++tc) {
+                    // candidates: the tiled implicit GEMM's tiles, then (tile >= 100) the weights-stationary 1x1 kernel's, then (>= 200) the 3x3's
+                    const int t = tc < kNumConvF8Tiles ? tc : (tc < kNumConvF8Tiles + kNumConvWs8Tiles ? 100 + (tc - kNumConvF8Tiles) : 200 + (tc - kNumConvF8Tiles - kNumConvWs8Tiles));
                     if (t < 100 && kIgemmTiles[t].bn > 32 && N <= 32) continue;
                     Step trial = s;
                     trial.tile = t;
-                    if (t >= 100 && !ConvWs8Eligible(MakeConvArgs(pi, trial), t - 100)) continue;
+                    if (t >= 200 ? !ConvWs38Eligible(MakeConvArgs(pi, trial), t - 200) : (t >= 100 && !ConvWs8Eligible(MakeConvArgs(pi, trial), t - 100))) continue;
                     LaunchStep(pi, trial, stream_);
                     float ms_best = 1e30f;
                     for (int rep = 0; rep < 3; ++rep) {
@@ -1396,8 +1396,11 @@ void DeviceModel::LaunchStep(const PlanInstance& pi, const Step& s_in, hipStream
                 // e4m3 tensors: only the fp8 kernel may touch them; a declined launch is an error, never a hand-over to a kernel that
                 // would read the bytes as floats
                 if (!w_->f8_ready) throw std::runtime_error("fp8 precision: scales are not calibrated yet");
-                if (s_in.tile >= 100) check(LaunchConvWs1x1F8(a, s_in.tile - 100, stream_), "conv1x1_ws_f8");        // weights-stationary 1x1 (kernels_ws8.hip)
-                else check(LaunchConvIgemmF8(a, s_in.tile, stream_), "conv_igemm_f8");
+                int t8 = s_in.tile;         // a weights-stationary launcher that declines these operands hands the step to the tiled fp8 kernel
+                if (t8 >= 200 ? !ConvWs38Eligible(a, t8 - 200) : (t8 >= 100 && !ConvWs8Eligible(a, t8 - 100))) t8 = s_in.base_tile < kNumConvF8Tiles ? s_in.base_tile : 3;
+                if (t8 >= 200) check(LaunchConvWs3x3F8(a, t8 - 200, stream_), "conv3x3_ws_f8");        // weights-stationary 3x3 (kernels_ws8.hip)
+                else if (t8 >= 100) check(LaunchConvWs1x1F8(a, t8 - 100, stream_), "conv1x1_ws_f8");   // weights-stationary 1x1
+                else check(LaunchConvIgemmF8(a, t8, stream_), "conv_igemm_f8");
                 break;
             }
             if (a.in.f8 || a.res.f8 || (a.out.f8 && s_in.algo != ConvAlgo::Stem)) throw std::runtime_error("internal error: fp8 tensor reached a non-fp8 conv kernel");
@@ -1480,6 +1483,7 @@ static std::string kernel_label(const Step& s) {
             if (s.algo == ConvAlgo::DenseBlock) return s.tile != 0 ? "dense_block_f16_kernel<" + std::to_string(s.parts.size() / 2) + " layers>" : "dense_block_parts<" + std::to_string(s.parts.size()) + " launches>";
             if (s.algo == ConvAlgo::DenseFused) return (s.tile >= 4 ? "conv_dense_fused_ws_kernel<t" : "conv_dense_fused_kernel<t") + std::to_string(s.tile) + ">";
             if (s.algo == ConvAlgo::DualF8) return s.in.f8 ? "conv1x1_ws_f8_kernel<dual,t" + std::to_string(s.tile >= 100 ? s.tile - 100 : 1) + ">" : "dual_f8_parts<2 launches>";
+            if (s.algo == ConvAlgo::IgemmF8 && s.tile >= 200) return "conv3x3_ws_f8_kernel<t" + std::to_string(s.tile - 200) + ">";
             if (s.algo == ConvAlgo::IgemmF8 && s.tile >= 100) return "conv1x1_ws_f8_kernel<t" + std::to_string(s.tile - 100) + ">";
             if (s.algo == ConvAlgo::IgemmF8)
                 return "conv_igemm_f8_kernel<" + std::to_string(kIgemmTiles[s.tile].bm) + "x" + std::to_string(kIgemmTiles[s.tile].bn) + ">";

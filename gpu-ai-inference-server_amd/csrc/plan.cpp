@@ -991,7 +991,14 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                 // ---- default choice without the autotuner (IE_AUTOTUNE=0, or before Prepare() has timed anything): the kernels
                 //      the exhaustive search picks for DenseNet / ResNet shapes ----
                 if (s.algo == ConvAlgo::IgemmF8) {
-                    if (const char* ft = std::getenv("IE_FORCE_TILE")) { int t = std::atoi(ft); if (t >= 0 && t < kNumIgemmBaseTiles && !(kIgemmTiles[t].bn > 32 && N <= 32)) s.tile = t; }
+                    if (const char* ft = std::getenv("IE_FORCE_TILE")) {
+                        const int t = std::atoi(ft);
+                        if (t >= 0 && t < kNumIgemmBaseTiles && !(kIgemmTiles[t].bn > 32 && N <= 32)) s.tile = t;
+                        // >= 100: the weights-stationary 1x1 kernel's tiles, >= 200: the 3x3's (kernels_ws8.hip); a launcher that declines the
+                        // operands hands the step back to the tiled kernel (executor)
+                        if (t >= 100 && t < 105 && n.kh == 1 && n.kw == 1 && n.sh == 1 && n.sw == 1) s.tile = t;
+                        if (t >= 200 && t < 204 && is3x3) s.tile = t;
+                    }
                     break;
                 }
                 if (!std::getenv("IE_FORCE_ALGO") && !std::getenv("IE_FORCE_TILE") && s.algo == ConvAlgo::IgemmVec) {

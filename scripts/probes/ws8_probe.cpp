@@ -4,6 +4,7 @@
 #include "../../gpu-ai-inference-server_amd/csrc/kernels_ws8.hip"
 #include "../../gpu-ai-inference-server_amd/csrc/kernels_f8.hip"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -25,7 +26,7 @@ int main(int argc, char** argv) {
     float *es, *bi;
     CK(hipMalloc(&in, M * K)); CK(hipMalloc(&in2, M * (K2 > 0 ? K2 : 32))); CK(hipMalloc(&res, M * N)); CK(hipMalloc(&out, M * N)); CK(hipMalloc(&out2, M * N));
     CK(hipMalloc(&w8, size_t(N) * K)); CK(hipMalloc(&w8b, size_t(N) * (K2 > 0 ? K2 : 32))); CK(hipMalloc(&es, N * 4)); CK(hipMalloc(&bi, N * 4));
-    std::vector<unsigned char> h(M * N);
+    std::vector<unsigned char> h(M * size_t(std::max(std::max(N, K), std::max(K2, 32))) + 64);
     for (size_t i = 0; i < h.size(); ++i) { unsigned v = unsigned(i * 2654435761u) >> 24; h[i] = (v & 0x7f) >= 0x78 ? (v & 0x87) | 0x30 : v; }   // finite e4m3 codes, |x| < 240
     CK(hipMemcpy(in, h.data(), M * K, hipMemcpyHostToDevice));
     CK(hipMemcpy(in2, h.data() + 17, M * (K2 > 0 ? K2 : 32), hipMemcpyHostToDevice));

@@ -1587,6 +1587,41 @@ def test_fp8_resnet_mini_every_tile(tmp_path, tile):
     assert e_emu < F8_EMU_RTOL and e_ref < F8_RTOL
 
 
+@pytest.mark.parametrize("tile", [100, 101, 102, 103, 104, 200, 201, 202, 203])
+def test_fp8_weights_stationary_kernels(tmp_path, tile):
+    """conv1x1_ws_f8_kernel (tiles 100-104, also its DUAL form for the projection shortcut of the first block) and conv3x3_ws_f8_kernel (tiles
+    200-203) forced on a bottleneck ResNet whose channel counts are multiples of 32 (every 1x1 / 3x3 stride-1 conv qualifies): against the fp8
+    plan emulation (same quantisation points: kernel correctness), the float64 oracle (stated fp8 bound) and the tiled fp8 kernel's answer."""
+    from oracle import fp8 as F
+    mb = models.resnet(3, layers=(2, 2), width=32, image=64, classes=20, seed=53)
+    path = models.write_repo(str(tmp_path), "resnet_f8w", mb)
+    x = models.synthetic_input((3, 3, 64, 64), stream="resnet_f8w")
+    ref = O.run(O.load_model(mb), {"data": x}, dtype=np.float64)["logits"]
+    env = dict(IE_FORCE_TILE=str(tile))
+
+    def kernels():
+        m = B.CreateModel(path, "resnet_f8w")
+        try:
+            din, _ = B.Prepare(m, [[3, 3, 64, 64]], 1)
+            B.CopyToDevice(m, din[0], x)
+            B.RunPrepared(m, 1, True)
+            return [p_["kernel"] for p_ in B.Profile(m, 1)]
+        finally:
+            m.Destroy()
+    y, info = _fp8_run(path, "resnet_f8w", x, "data", "logits", [3, 20], env)
+    y0, _ = _fp8_run(path, "resnet_f8w", x, "data", "logits", [3, 20], dict(IE_FORCE_TILE="3"))
+    kern = _run_with_env(dict(IE_PRECISION="fp8", **env), kernels)
+    want = "conv1x1_ws_f8_kernel" if tile < 200 else "conv3x3_ws_f8_kernel"
+    nws = sum(k.startswith(want) for k in kern)
+    assert nws >= (4 if tile < 200 else 2), kern         # (the strided 3x3 of a stage's first block stays on the tiled kernel)
+    assert any(k.startswith("conv1x1_ws_f8_kernel<dual") for k in kern), kern          # the first block's projection shortcut: one launch, two GEMMs
+    plan, blob = _run_with_env(dict(IE_PRECISION="fp8", **env), lambda: (B.DescribeModel(path, 3)["plan"], B.PlanWeights(path, 3)))
+    emu = F.run_plan(plan, blob, {"data": x}, act_scales=info["f8_act_scales"], fp8=True)["logits"]
+    e_emu, e_ref, e_t = rel_err(y, emu), rel_err(y, ref), rel_err(y, y0)
+    print(f"fp8 weights-stationary tile {tile}: {nws} launches; vs fp8 emulation {e_emu:.2e}, vs float64 oracle {e_ref:.2e}, vs the tiled kernels {e_t:.2e}")
+    assert e_emu < F8_EMU_RTOL and e_ref < F8_RTOL_MINI and e_t < F8_EMU_RTOL
+
+
 def test_fp8_deep_resnet_mini_vs_float64_oracle(tmp_path):
     """Four stages, 18 convs, final maps of 2x2: quantisation error against float64 within the stated bound."""
     from oracle import fp8 as F

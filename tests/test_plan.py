@@ -272,8 +272,16 @@ def test_fp8_plan_structure_and_rejections(tmp_path, densenet_repo, monkeypatch)
     assert p["precision"] == "fp8"
     convs = [s for s in p["steps"] if s["kind"] == "conv"]
     assert convs[0]["algo"] == "stem" and not convs[0]["in"]["f8"] and convs[0]["out"]["f8"]
-    assert all(s["algo"] == "igemm_f8" and s["in"]["f8"] and s["out"]["f8"] for s in convs[1:-1]) and len(convs) == 54
-    assert sum(1 for s in convs if s["residual"]) == 16 and all(s["in2"]["f8"] for s in convs if s["residual"])
+    # 53 convs + the classifier; the projection shortcut of stage 1 and the block's last 1x1 are ONE step (two GEMMs of one launch:
+    # the shortcut tensor is never written), the strided projections of stages 2-4 keep their own step
+    dual = [s for s in convs if s["algo"] == "dual_f8"]
+    assert len(dual) == 1 and len(dual[0]["parts"]) == 2 and not dual[0]["residual"] and dual[0]["parts"][1]["residual"] and dual[0]["parts"][0]["stride"] == [1, 1]
+    assert all(s["algo"] in ("igemm_f8", "dual_f8") and s["in"]["f8"] and s["out"]["f8"] for s in convs[1:-1]) and len(convs) == 53
+    assert sum(1 for s in convs if s["residual"]) == 15 and all(s["in2"]["f8"] for s in convs if s["residual"])
+    monkeypatch.setenv("IE_NO_DUAL_F8", "1")
+    convs1 = [s for s in B.DescribeModel(path, 4)["plan"]["steps"] if s["kind"] == "conv"]
+    assert len(convs1) == 54 and sum(1 for s in convs1 if s["residual"]) == 16 and not [s for s in convs1 if s["algo"] == "dual_f8"]
+    monkeypatch.delenv("IE_NO_DUAL_F8")
     gap = [s for s in p["steps"] if s["kind"] == "gap"][0]
     assert gap["in"]["f8"] and gap["out"]["f16"] and convs[-1]["in"]["f16"] and not convs[-1]["out"]["f16"] and not convs[-1]["out"]["f8"]
     assert all(s["in_src"] >= 0 for s in p["steps"][1:]) and p["steps"][0]["in_src"] == -1
