@@ -74,14 +74,28 @@ __device__ __forceinline__ h8 pk_max8(h8 v, h8 lo) {
 // every wait in the loop collapses to "all outstanding loads".
 template <int CFG>
 __global__ __launch_bounds__(512) void dense_block_f16_kernel(const DenseBlockArgs a) {
-    constexpr int TM = CFG == 0 ? 7 : 2;                   // position tiles per image at most
-    constexpr int PITP = CFG == 0 ? 7 : 2;                 // 16-byte pieces per producer thread and chunk (rows tp / 8 + 32 i)
-    constexpr int T3 = CFG == 0 ? 2 : 1;                   // 3x3: position tiles per consumer wave
+    constexpr bool BAND = CFG == 2;                        // a workgroup owns a BAND of rows of one image (one layer per launch, the bottleneck's halo rows recomputed)
+    constexpr int TM = CFG == 0 ? 7 : (CFG == 1 ? 2 : 8);  // staged position tiles at most
+    constexpr int PITP = TM;                               // 16-byte pieces per producer thread and chunk (rows tp / 8 + 32 i)
+    constexpr int T3 = CFG == 1 ? 1 : 2;                   // 3x3: position tiles per consumer wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_blk[];
 
-    const int H = a.h, W = a.w, PW = W + 1, NP = H * PW;
-    const int ntiles = (NP + 31) >> 5;
-    const int trows = NP + 2 * PW + 2;
+    // Raster geometry.  Whole-image mode: the H image rows are staged, T holds them between one zero row above and below (a staged position p
+    // sits at raster row p + PW + 1).  Band mode: rows y0 - 1 .. y0 + R of the image are staged -- the halo rows too, their bottleneck values are
+    // recomputed by this workgroup; rows outside the image stay zero -- and p sits at raster row p + 1.  Either way output position q (row q / PW
+    // of the band, column q % PW) reads raster rows q + ky * PW + kx.
+    const int H = a.h, W = a.w, PW = W + 1;
+    const int R = BAND ? a.band_rows : H;
+    const int nbands = BAND ? (H + R - 1) / R : 1;
+    const int img = BAND ? int(blockIdx.x) / nbands : int(blockIdx.x);
+    const int y0 = BAND ? (int(blockIdx.x) - img * nbands) * R : 0;          // first output row of this workgroup
+    const int ys = BAND ? y0 - 1 : 0;                                        // image row of staged row 0
+    const int NP = (BAND ? R + 2 : H) * PW;                                  // staged positions (1x1)
+    const int Rb = H - y0 < R ? H - y0 : R;                                  // output rows that exist
+    const int NP3 = Rb * PW;                                                 // output positions (3x3)
+    const int ntiles = (NP + 31) >> 5, ntiles3 = (NP3 + 31) >> 5;
+    const int toff = BAND ? 1 : PW + 1;
+    const int trows = BAND ? NP + 2 : NP + 2 * PW + 2;
     _Float16* const sT = reinterpret_cast<_Float16*>(smem_blk);                              // [trows][kTPitch]
     unsigned char* const sS = smem_blk + size_t(trows) * kTPitch * 2;                        // staging: two activation chunks; then all 3x3 weights
     _Float16* const sA0 = reinterpret_cast<_Float16*>(sS);
@@ -94,7 +108,6 @@ __global__ __launch_bounds__(512) void dense_block_f16_kernel(const DenseBlockAr
 
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int img = blockIdx.x;
     const int pitch = a.pitch;
     _Float16* const ximg = a.x + size_t(img) * H * W * pitch;
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(ximg, 0, H * W * pitch * 2, 0x00020000);
@@ -119,8 +132,8 @@ __global__ __launch_bounds__(512) void dense_block_f16_kernel(const DenseBlockAr
 #pragma unroll
         for (int i = 0; i < PITP; ++i) {
             const int p = (tp >> 3) + 32 * i;
-            const int y = p / PW, x = p - y * PW;
-            poff[i] = (p < NP && x < W) ? (y * W + x) * pitch + a.in_coff + c8 : -1;
+            const int y = p / PW, x = p - y * PW, iy = ys + y;
+            poff[i] = (p < NP && x < W && iy >= 0 && iy < H) ? (iy * W + x) * pitch + a.in_coff + c8 : -1;
         }
         struct ASlot { u32x4 v[PITP]; };
         ASlot ra[3];
@@ -235,16 +248,16 @@ __global__ __launch_bounds__(512) void dense_block_f16_kernel(const DenseBlockAr
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int p = i * 32 + r;
-            const int y = p / PW, x = p - y * PW;
-            if (p < NP && x < W) vmask |= 1u << i;
+            const int y = p / PW, x = p - y * PW, iy = ys + y;
+            if (p < NP && x < W && iy >= 0 && iy < H) vmask |= 1u << i;
         }
         unsigned orow3[T3];                                // 3x3: byte offset of the lane's output pixel row, or out of range
 #pragma unroll
         for (int j = 0; j < T3; ++j) {
-            const int t = (CFG == 0 ? wave * T3 : wave) + j;
+            const int t = (CFG != 1 ? wave * T3 : wave) + j;
             const int p = t * 32 + r;
             const int y = p / PW, x = p - y * PW;
-            orow3[j] = (t < ntiles && (CFG == 0 || wave < 2) && p < NP && x < W) ? unsigned((y * W + x) * pitch) * 2u : kOOB;
+            orow3[j] = (t < ntiles3 && (CFG != 1 || wave < 2) && p < NP3 && x < W) ? unsigned(((y0 + y) * W + x) * pitch) * 2u : kOOB;
         }
         struct BSlot { u32x4 f[4]; };
         BSlot bs[3];
@@ -333,7 +346,7 @@ __global__ __launch_bounds__(512) void dense_block_f16_kernel(const DenseBlockAr
                         const auto s0 = __builtin_amdgcn_permlane32_swap(xa[0], xb[0], false, false);
                         const auto s1 = __builtin_amdgcn_permlane32_swap(xa[1], xb[1], false, false);
                         if ((vmask >> i) & 1u)
-                            *reinterpret_cast<u32x4*>(sT + (i * 32 + r + PW + 1) * kTPitch + np * 32 + 8 * (2 * gp + hh)) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                            *reinterpret_cast<u32x4*>(sT + (i * 32 + r + toff) * kTPitch + np * 32 + 8 * (2 * gp + hh)) = u32x4{s0[0], s1[0], s0[1], s1[1]};
                     }
                 }
             }
@@ -346,8 +359,8 @@ __global__ __launch_bounds__(512) void dense_block_f16_kernel(const DenseBlockAr
                 issue_b(bs[2], Ln, 2);
             }
             // ---------------- 3x3: nine shifted GEMMs out of the raster; CFG 0: wave w owns tiles 2w, 2w + 1 (one weight fragment feeds both) ----------------
-            const int t0 = CFG == 0 ? wave * T3 : wave;
-            if (t0 < ntiles && (CFG == 0 || wave < 2)) {
+            const int t0 = CFG != 1 ? wave * T3 : wave;
+            if (t0 < ntiles3 && (CFG != 1 || wave < 2)) {
                 f32x16 acc3[T3];
 #pragma unroll
                 for (int j = 0; j < T3; ++j)
@@ -419,22 +432,34 @@ __global__ __launch_bounds__(512) void dense_block_f16_kernel(const DenseBlockAr
     }
 }
 
-static size_t block_lds_bytes(int H, int W) {
-    const int PW = W + 1, NP = H * PW, trows = NP + 2 * PW + 2;
-    const size_t stage = size_t(kW3Bytes);
+static size_t block_lds_bytes(int cfg, int H, int W, int R) {
+    const int PW = W + 1;
+    const int trows = cfg == 2 ? (R + 2) * PW + 2 : H * PW + 2 * PW + 2;
+    const size_t stage = std::max(size_t(kW3Bytes), size_t(2) * 32 * (cfg == 0 ? 7 : (cfg == 1 ? 2 : 8)) * kAPitch * 2);
     return size_t(trows) * kTPitch * 2 + stage + 2 * 160 * sizeof(float) + size_t(4) * kMaxK * 2;
 }
 
-static int block_cfg(int H, int W) {
-    const int ntiles = (H * (W + 1) + 31) / 32;
-    return ntiles <= 2 ? 1 : (ntiles <= 7 ? 0 : -1);
+// 0 / 1: one workgroup per image (7 / 2 position tiles at most); 2: bands of `*rows` image rows with the halo recomputed (one layer per launch)
+static int block_cfg(int H, int W, int nlayers, int* rows) {
+    const int PW = W + 1, ntiles = (H * PW + 31) / 32;
+    *rows = 0;
+    if (ntiles <= 2) return 1;
+    if (ntiles <= 7) return 0;
+    if (nlayers != 1) return -1;
+    int R = 256 / PW - 2;                      // (R + 2) * PW staged positions in 8 tiles
+    if (R > H) R = H;
+    if (R < 1) return -1;
+    *rows = R;
+    return 2;
 }
 
 bool DenseBlockEligible(const DenseBlockArgs& a) {
     if (a.x == nullptr || a.wfrag16 == nullptr || a.w16 == nullptr || a.w32 == nullptr) return false;
     if (a.nlayers < 1 || a.nlayers > kMaxBlockLayers || a.n < 1 || a.h < 1 || a.w < 1) return false;
-    const int cfg = block_cfg(a.h, a.w);
-    if (cfg < 0 || block_lds_bytes(a.h, a.w) > size_t(160) * 1024) return false;
+    int rows = 0;
+    const int cfg = block_cfg(a.h, a.w, a.nlayers, &rows);
+    if (cfg < 0 || block_lds_bytes(cfg, a.h, a.w, rows) > size_t(160) * 1024) return false;
+    if (int64_t(a.n) * ((cfg == 2 ? (a.h + rows - 1) / rows : 1)) >= (int64_t(1) << 31)) return false;
     if ((a.pitch & 7) || (a.in_coff & 7) || (reinterpret_cast<uintptr_t>(a.x) & 15) || (reinterpret_cast<uintptr_t>(a.wfrag16) & 15) ||
         (reinterpret_cast<uintptr_t>(a.w16) & 15))
         return false;
@@ -453,12 +478,16 @@ bool DenseBlockEligible(const DenseBlockArgs& a) {
     return true;
 }
 
-hipError_t LaunchDenseBlockF16(const DenseBlockArgs& a, hipStream_t stream) {
-    if (!DenseBlockEligible(a)) return hipErrorInvalidValue;
-    const int cfg = block_cfg(a.h, a.w);
-    const size_t lds = block_lds_bytes(a.h, a.w);
-    if (cfg == 0) dense_block_f16_kernel<0><<<dim3(a.n), dim3(512), lds, stream>>>(a);
-    else dense_block_f16_kernel<1><<<dim3(a.n), dim3(512), lds, stream>>>(a);
+hipError_t LaunchDenseBlockF16(const DenseBlockArgs& a_in, hipStream_t stream) {
+    if (!DenseBlockEligible(a_in)) return hipErrorInvalidValue;
+    DenseBlockArgs b = a_in;
+    int rows = 0;
+    const int cfg = block_cfg(b.h, b.w, b.nlayers, &rows);
+    const size_t lds = block_lds_bytes(cfg, b.h, b.w, rows);
+    b.band_rows = rows;
+    if (cfg == 0) dense_block_f16_kernel<0><<<dim3(b.n), dim3(512), lds, stream>>>(b);
+    else if (cfg == 1) dense_block_f16_kernel<1><<<dim3(b.n), dim3(512), lds, stream>>>(b);
+    else dense_block_f16_kernel<2><<<dim3(b.n * ((b.h + rows - 1) / rows)), dim3(512), lds, stream>>>(b);
     return hipGetLastError();
 }
 
@@ -486,6 +515,7 @@ hipError_t InitKernelsBlock() {
     hipError_t e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_block_f16_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_block_f16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_block_f16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     return hipSuccess;
 }
 

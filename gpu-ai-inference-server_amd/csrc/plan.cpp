@@ -1241,8 +1241,10 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
             if (s1.in.c < 64 || s1.in.c % 32 || s1.in.pitch % 8 || s1.in.c_off % 8 || s3.out.c_off % 8) return false;
             if (s3.out.c_off < s1.in.c_off + s1.in.c && s3.out.c_off + 32 > s1.in.c_off) return false;
             if ((s1.pre_scale_off >= 0) != (s1.pre_shift_off >= 0)) return false;
+            // up to 7 raster tiles: a workgroup per image (chains of layers); larger maps: bands of rows, one layer per launch, while at least one
+            // row + halo fits the 8 staged tiles
             const int64_t ntiles = (s1.in.h * (s1.in.w + 1) + 31) / 32;
-            if (ntiles > 7) return false;
+            if (ntiles > 7 && 256 / (s1.in.w + 1) < 3) return false;
             // T must have no other reader: the fused kernel never writes it to memory
             for (size_t j = i + 2; j < plan.steps.size(); ++j) {
                 const Step& q = plan.steps[j];
@@ -1257,6 +1259,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
             size_t n = 0;
             while (n < 24 && layer_at(i + 2 * n)) {
                 if (n > 0) {
+                    if ((plan.steps[i].in.h * (plan.steps[i].in.w + 1) + 31) / 32 > 7) break;       // band mode: one layer per launch
                     const Step& f1 = plan.steps[i], &c1 = plan.steps[i + 2 * n], &p3 = plan.steps[i + 2 * n - 1];
                     if (c1.in.buf != f1.in.buf || c1.in.pitch != f1.in.pitch || c1.in.c_off != f1.in.c_off || c1.in.n != f1.in.n || c1.in.h != f1.in.h || c1.in.w != f1.in.w)
                         break;
@@ -1268,7 +1271,11 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
             if (n == 0) { blocksteps.push_back(plan.steps[i]); ++i; continue; }
             Step f = plan.steps[i];
             f.algo = ConvAlgo::DenseBlock;
-            f.tile = 1;
+            // band mode (maps of more than 7 raster tiles, one layer per launch) measured no faster than the two streaming kernels at batch 128
+            // (28x28: 39-58 vs 42-54 us per layer; 56x56: 160-218 vs 93-123 us: the per-band fixed cost -- 72 KB of 3x3 weights into LDS, raster
+            // reset, epilogue -- is paid 5 ... 28 times per image): the parts are the default there, the search may still pick the launch
+            f.tile = (plan.steps[i].in.h * (plan.steps[i].in.w + 1) + 31) / 32 > 7 ? 0 : 1;
+            if (const char* e = std::getenv("IE_DENSE_BAND"); e && std::atoi(e) != 0) f.tile = 1;       // tests: band mode on by default
             f.splitk = 1;
             f.flops = 0;
             f.bytes = 0;

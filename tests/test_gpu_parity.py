@@ -865,12 +865,15 @@ def test_fp16_random_conv_graphs_vs_oracle(tmp_path, seed):
     print(f"fp16 seed {seed}: worst rel err {worst:.2e}")
 
 
-@pytest.mark.parametrize("batch,image,stem,blocks", [(3, 56, 128, (4, 3)), (5, 56, 256, (2, 5)), (2, 28, 192, (6,)), (9, 112, 192, (2, 4, 3))])
-def test_fp16_dense_block_chain_kernel(tmp_path, batch, image, stem, blocks):
+@pytest.mark.parametrize("batch,image,stem,blocks,band", [(3, 56, 128, (4, 3), 0), (5, 56, 256, (2, 5), 0), (2, 28, 192, (6,), 0), (9, 112, 192, (2, 4, 3), 0),
+                                                        (3, 112, 64, (3, 2), 1), (2, 224, 64, (2, 2, 2), 1), (5, 80, 96, (2, 3), 1)])
+def test_fp16_dense_block_chain_kernel(tmp_path, batch, image, stem, blocks, band):
     """dense_block_f16_kernel (kernels_block.hip): chains of dense layers (BN-ReLU-1x1 to 128, BN-ReLU-3x3 to 32) on 14x14 / 7x7 maps run as ONE
     launch per chain, one workgroup per image, the bottleneck tensor never leaving LDS.  DenseNet-shaped graphs whose blocks start at K0 =
     128 ... 256 channels (odd and even chunk counts, K % 64 == 32 tails, 7- and 2-tile maps, ragged chains cut where a layer would read what
-    its predecessor writes too early): against the float64 oracle within F16_RTOL, and against the same plan run layer by layer."""
+    its predecessor writes too early): against the float64 oracle within F16_RTOL, and against the same plan run layer by layer.
+    band = 1 (IE_DENSE_BAND): the band mode of the same kernel on 56x56 / 28x28 / 20x20 maps -- a workgroup per band of image rows, one layer
+    per launch, the bottleneck's halo rows recomputed, ragged last bands -- which the planner leaves to the search by default."""
     mb = models.densenet(batch, growth=32, blocks=blocks, stem=stem, image=image, classes=24, seed=91)
     path = models.write_repo(str(tmp_path), "dblock", mb)
     x = models.synthetic_input((batch, 3, image, image), stream="dblock")
@@ -886,9 +889,11 @@ def test_fp16_dense_block_chain_kernel(tmp_path, batch, image, stem, blocks):
             return y, [p_["kernel"] for p_ in B.Profile(m, 1)], B.DescribeModel(path, batch)["plan"]
         finally:
             m.Destroy()
-    y, kern, plan = _run_with_env(_f16_env(IE_AUTOTUNE="0"), go)
+    y, kern, plan = _run_with_env(_f16_env(IE_AUTOTUNE="0", IE_DENSE_BAND=str(band)), go)
     y0, kern0, plan0 = _run_with_env(_f16_env(IE_AUTOTUNE="0", IE_NO_DENSE_BLOCK="1"), go)
-    chains = [s for s in plan["steps"] if s.get("algo") == "dense_block"]
+    chains = [s for s in plan["steps"] if s.get("algo") == "dense_block" and s["tile"] != 0]
+    if band:
+        assert any(s["in"]["h"] * (s["in"]["w"] + 1) > 224 for s in chains), [(s["in"]["h"], s["in"]["w"]) for s in chains]
     assert chains and not [s for s in plan0["steps"] if s.get("algo") == "dense_block"]
     assert all(len(s["parts"]) % 2 == 0 and s["parts"][0]["k"] == [1, 1] and s["parts"][1]["k"] == [3, 3] for s in chains)
     nk = [k for k in kern if k.startswith("dense_block_f16_kernel")]
