@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak
+SUSTAINED_FP32_MFMA_TFLOPS = 129.0  # what a chip full of v_mfma_f32_32x32x2_f32 sustains (65.5 cycles per issue at 1.97 GHz: profiles/r02/probe_mfma_rate.txt)
 PEAK_FP16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense fp16/bf16 matrix peak (no sparsity)
 PEAK_HBM_GBS = 8000.0
 
@@ -191,7 +192,10 @@ def measure(B, models, sharding, *, model_name, dtype, Bsz, steps, warmup, rank,
             "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"{arch} {DTYPES[dtype][1]} batch={Bsz} per GPU, synthetic 3x224x224 inputs ({cfg_name}); "
                                    "synthetic ONNX graph + seeded random weights (reference model file is not in the mount)",
-                       "global_batch": Bsz * world, "per_gpu_batch": Bsz, "parallelism": f"dp{world} (independent batch shards)"},
+                       "global_batch": Bsz * world, "per_gpu_batch": Bsz, "parallelism": f"dp{world} (independent batch shards)",
+                       "scaling_note": "weak scaling: every rank runs the SAME per-GPU batch, so N ranks are expected at ~N x this value (no data-path "
+                                       "collective); a FIXED global batch of 32 cut over 8 GPUs (4 images each, ~1.0 ms per step against 2.2 ms for 32) "
+                                       "would scale ~2.2x, not 8x: DESIGN.md section 6"},
             "p50_ms": round(p50, 4),
         }
         # ---- roofline of the dominant kernel family, HIP events on the model's stream --------------------------
@@ -221,6 +225,9 @@ def measure(B, models, sharding, *, model_name, dtype, Bsz, steps, warmup, rank,
                   "flops_per_launch": round(d["flops"] / d["launches"], 1), "avg_launch_ms": round(d["ms"] / d["launches"], 6),
                   "achieved_tflops": round(achieved, 3), "achieved_gbs": round(achieved_gbs, 1),
                   "frac_of_mfma_peak": round(frac_mfma, 4), "frac_of_hbm_peak": round(frac_hbm, 4)}
+        if dtype in ("f32", "f32x6"):
+            common["sustained_peak_tflops"] = SUSTAINED_FP32_MFMA_TFLOPS      # `peak` stays the guide's 157.3; this is the measured ceiling
+            common["frac_of_sustained_peak"] = round(achieved / SUSTAINED_FP32_MFMA_TFLOPS, 4)
         if frac_mfma >= frac_hbm:      # the ceiling this kernel family is closer to is the one that bounds it
             result["roofline"] = {"bound": "mfma", "achieved": round(achieved, 3), "peak": mfma_peak, "unit": "TFLOP/s", "frac": round(frac_mfma, 4)}
         else:
@@ -265,6 +272,9 @@ def measure(B, models, sharding, *, model_name, dtype, Bsz, steps, warmup, rank,
                     result[f"binding{tag}_p50_ms"] = round(float(np.percentile(hl, 50)) * 1e3, 3)
             info = B.RuntimeInfo(model)
             result["modelinfer_pipeline"] = {"chunks": info["last_chunks"], "head_steps": info["last_head_steps"]}
+            # co-headline: what the unchanged Go server sees through the C ABI (host buffers, PCIe-inclusive) beside the device-resident `value`
+            result["metric"] += (f"; through ModelInfer with host FLOAT32 payloads {result['modelinfer_images_per_s']:.0f} images/sec "
+                                 f"(p50 {result['modelinfer_p50_ms']:.3f} ms), UINT8 payloads {result['modelinfer_uint8_images_per_s']:.0f} images/sec")
         return result
     finally:
         model.Destroy()

@@ -36,6 +36,7 @@
 #include <rccl/rccl.h>
 
 #include "config.h"
+#include "env.h"
 #include "executor.h"
 #include "kernels.h"
 #include "onnx_reader.h"
@@ -58,7 +59,8 @@ struct Roctx {
     int (*push)(const char*) = nullptr;
     int (*pop)() = nullptr;
     Roctx() {
-        const char* e = std::getenv("IE_ROCTX");
+        const ie::Env env = ie::Env::Read();
+        const char* e = env.get("IE_ROCTX");
         if (!e || e[0] != '1') return;
         for (const char* name : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
             if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
@@ -343,6 +345,7 @@ bool ModelObj::Load() {
         case MODEL_CUSTOM: SetError("Custom model loading not implemented"); break;
         case MODEL_ONNX: {
             try {
+                const ie::Env env = ie::Env::Read();       // this load's switches, read once
                 const std::string file = path + "/model.onnx";
                 if (!std::filesystem::exists(file, ec)) {
                     SetError("ONNX model file not found: " + file);
@@ -360,7 +363,7 @@ bool ModelObj::Load() {
                 ie::Precision prec = ie::Precision::F32;
                 {
                     std::string want = conf.precision;
-                    if (const char* e = std::getenv("IE_PRECISION")) want = e;
+                    if (const char* e = env.get("IE_PRECISION")) want = e;
                     for (auto& ch : want) ch = char(std::tolower(static_cast<unsigned char>(ch)));
                     if (want == "fp16" || want == "f16" || want == "half" || want == "float16") prec = ie::Precision::F16;
                     else if (want == "fp8" || want == "f8" || want == "e4m3" || want == "float8") prec = ie::Precision::F8;
@@ -396,7 +399,7 @@ bool ModelObj::Load() {
                 for (auto& vi : inf.outputs) if (vi.dims.empty() || vi.dims[0] > 0) symbolic_batch = false;
                 {
                     std::vector<int64_t> tb = conf.tune_batches;
-                    if (const char* e = std::getenv("IE_TUNE_BATCHES")) {
+                    if (const char* e = env.get("IE_TUNE_BATCHES")) {
                         tb.clear();
                         std::stringstream ss(e);
                         std::string tok;
@@ -411,22 +414,22 @@ bool ModelObj::Load() {
                 }
                 // ---- shard replicas and extra lanes ----
                 std::vector<int> shard_ids;                       // devices of lanes[1 .. num_shards)
-                if (const char* e = std::getenv("IE_SHARD_DEVICES")) {
+                if (const char* e = env.get("IE_SHARD_DEVICES")) {
                     std::stringstream ss(e);
                     std::string tok;
                     while (std::getline(ss, tok, ',')) if (!tok.empty()) shard_ids.push_back(std::atoi(tok.c_str()));
                     if (!shard_ids.empty()) shard_ids.erase(shard_ids.begin());           // the first id is the primary's slice
                 } else {
                     int n = conf.gpus > 0 ? conf.gpus : 1;
-                    if (const char* e = std::getenv("IE_GPUS")) n = std::atoi(e);
+                    if (const char* e = env.get("IE_GPUS")) n = std::atoi(e);
                     const int have = ie::HipDeviceCount();
                     for (int k = 1; k < n && device_id + k < have; ++k) shard_ids.push_back(device_id + k);
                 }
                 if (!symbolic_batch) shard_ids.clear();           // a fixed-batch graph cannot be sliced
                 int instances = conf.instance_count > 0 ? conf.instance_count : (cfg_instances > 0 ? cfg_instances : 1);
-                if (const char* e = std::getenv("IE_INSTANCES")) instances = std::atoi(e);
+                if (const char* e = env.get("IE_INSTANCES")) instances = std::atoi(e);
                 instances = std::max(1, std::min(instances, 16));
-                const bool private_weights = [] { const char* e = std::getenv("IE_SHARD_PRIVATE_WEIGHTS"); return e && e[0] == '1'; }();
+                const bool private_weights = [&] { const char* e = env.get("IE_SHARD_PRIVATE_WEIGHTS"); return e && e[0] == '1'; }();
                 std::vector<std::unique_ptr<ie::DeviceModel>> built;
                 built.push_back(std::move(primary));
                 struct Spec { int dev; bool shard; };
@@ -480,9 +483,9 @@ bool ModelObj::Load() {
                 {   // batching knobs: environment first, then config.json, then ModelCreate's ModelConfig
                     max_batch = cfg_max_batch;
                     if (conf.dynamic_batching && conf.max_batch_size > 1) max_batch = conf.max_batch_size;
-                    if (const char* e = std::getenv("IE_DYNAMIC_BATCH")) max_batch = std::atoi(e);
+                    if (const char* e = env.get("IE_DYNAMIC_BATCH")) max_batch = std::atoi(e);
                     if (conf.batch_window_us >= 0) batch_window_us = conf.batch_window_us;
-                    if (const char* e = std::getenv("IE_BATCH_WINDOW_US")) batch_window_us = std::max(0, std::atoi(e));
+                    if (const char* e = env.get("IE_BATCH_WINDOW_US")) batch_window_us = std::max(0, std::atoi(e));
                     if (max_batch > 4096) max_batch = 4096;
                 }
                 onnx = parsed;
@@ -579,7 +582,7 @@ bool InferenceLoadModel(InferenceManagerHandle handle, const char* model_name, c
             obj->type = MODEL_ONNX;
             obj->device = DEVICE_GPU;      // bridge:346-347: GPU, device 0
             obj->device_id = 0;
-            if (const char* d = std::getenv("IE_DEVICE_ID")) obj->device_id = std::atoi(d);
+            if (const char* d = ie::Env::Read().get("IE_DEVICE_ID")) obj->device_id = std::atoi(d);
             obj->name = name;
             obj->version = ver.empty() ? handle->repo->LatestVersion(name) : ver;
             obj->input_names = {"input"};
@@ -1272,7 +1275,8 @@ char* EngineDescribeModel(const char* path, int batch, ErrorMessage* error) {
                 shapes.push_back(s);
             }
             ie::Precision prec = ie::Precision::F32;       // the planner is host code: IE_PRECISION selects what to describe
-            if (const char* e = std::getenv("IE_PRECISION")) {
+            const ie::Env env = ie::Env::Read();
+            if (const char* e = env.get("IE_PRECISION")) {
                 std::string w = e;
                 if (w == "fp16" || w == "f16" || w == "half") prec = ie::Precision::F16;
                 else if (w == "fp8" || w == "f8" || w == "e4m3") prec = ie::Precision::F8;
@@ -1338,7 +1342,13 @@ bool EngineRunPrepared(ModelHandle handle, int iters, int sync, ErrorMessage* er
         ModelObj& M = *handle->model;
         Lane0 L0(M);
         if (!L0.dev() || !L0.dev()->current()) { set_error(error, "Model not prepared"); return false; }
-        for (int i = 0; i < iters; ++i) L0.dev()->Enqueue(*L0.dev()->current());
+        // IE_MAX_INFLIGHT_REPLAYS=n: synchronise every n replays (a profiler's per-dispatch bookkeeping under deep un-synchronised graph
+        // queues crashed rocprofv3 --kernel-trace: profiles/r02/graph_burst_under_kernel_trace_sigsegv.log); default: no cap
+        const int cap = L0.dev()->max_inflight_replays();
+        for (int i = 0; i < iters; ++i) {
+            L0.dev()->Enqueue(*L0.dev()->current());
+            if (cap > 0 && (i + 1) % cap == 0) L0.dev()->Synchronize();
+        }
         if (sync) L0.dev()->Synchronize();
         return true;
     } catch (const std::exception& e) { set_error(error, e.what()); return false; }

@@ -1,4 +1,5 @@
 #include "executor.h"
+#include "env.h"
 
 #include <algorithm>
 #include <cstdint>
@@ -127,6 +128,9 @@ void load_tune_file(const std::string& path, std::map<std::vector<int64_t>, std:
 
 DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id, const DeviceModelOptions& opt)
     : model_(std::move(model)), device_(device_id), precision_(opt.precision) {
+    env_ = Env::Read();
+    SetLaunchKnobs(env_);
+    max_inflight_replays_ = std::max(0, env_.integer("IE_MAX_INFLIGHT_REPLAYS", 0));
     int n = HipDeviceCount();
     if (n <= 0) throw std::runtime_error("No HIP device available: the MI355X engine has no CPU fallback");
     if (device_id < 0 || device_id >= n) throw std::runtime_error("Invalid device id " + std::to_string(device_id));
@@ -148,7 +152,7 @@ DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id, 
     });
     check(g_kernels_err, "InitKernels");
     fp32_split_ = opt.fp32_split && opt.precision == Precision::F32;
-    if (const char* e = std::getenv("IE_FP32_SPLIT")) fp32_split_ = std::atoi(e) != 0 && opt.precision == Precision::F32;
+    if (const char* e = env_.get("IE_FP32_SPLIT")) fp32_split_ = std::atoi(e) != 0 && opt.precision == Precision::F32;
     if (opt.share) {
         if (opt.share->device != device_) throw std::runtime_error("internal error: shared weights live on another device");
         w_ = opt.share;
@@ -159,7 +163,7 @@ DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id, 
         owns_weights_ = true;
         // Persistent kernel-choice cache: IE_TUNE_CACHE=<file> (""/"0" = none), else the path the bridge derived from the model directory.
         std::string path = opt.tune_cache_path;
-        if (const char* tc = std::getenv("IE_TUNE_CACHE")) path = (tc[0] == 0 || (tc[0] == '0' && tc[1] == 0)) ? std::string() : std::string(tc);
+        if (const char* tc = env_.get("IE_TUNE_CACHE")) path = (tc[0] == 0 || (tc[0] == '0' && tc[1] == 0)) ? std::string() : std::string(tc);
         if (fp32_split_ && !path.empty()) path += ".x6";       // choices made with the bf16x6 kernels in the search are their own file
         w_->tune_cache_path = path;
         if (!path.empty()) load_tune_file(path, w_->tune_cache);
@@ -171,18 +175,18 @@ DeviceModel::DeviceModel(std::shared_ptr<const OnnxModel> model, int device_id, 
     for (auto& e : h2d_events_) check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
     check(hipEventCreate(&t0_event_), "hipEventCreate");
     check(hipEventCreate(&t1_event_), "hipEventCreate");
-    const char* ng = std::getenv("IE_DISABLE_GRAPH");
+    const char* ng = env_.get("IE_DISABLE_GRAPH");
     use_graph_ = !(ng && ng[0] == '1');
-    const char* at = std::getenv("IE_AUTOTUNE");
+    const char* at = env_.get("IE_AUTOTUNE");
     // Measured on MI355X (DenseNet-121 B=32): the in-launch combine (agent-scope release/acquire per tile) costs more than
     // the kernel boundary it removes: 3.63 ms/step vs 3.42 ms/step with the separate reduce kernel.  Two-pass is the default.
-    const char* tp = std::getenv("IE_SPLITK_IN_LAUNCH");
+    const char* tp = env_.get("IE_SPLITK_IN_LAUNCH");
     two_pass_splitk_ = !(tp && tp[0] == '1');
-    autotune_ = !(at && at[0] == '0') && !std::getenv("IE_FORCE_TILE") && !std::getenv("IE_FORCE_SPLITK") && !std::getenv("IE_FORCE_ALGO");
-    if (const char* od = std::getenv("IE_TUNE_ON_DEMAND")) tune_on_demand_ = od[0] == '1';
-    if (const char* pc = std::getenv("IE_PIPELINE_CHUNKS")) pipeline_chunks_ = std::max(0, std::min(kMaxChunks, std::atoi(pc)));
-    if (const char* ph = std::getenv("IE_PIPELINE_HEAD")) pipeline_head_ = std::max(0, std::atoi(ph));
-    if (const char* mp = std::getenv("IE_MAX_PLANS")) max_plans_ = size_t(std::max(1, std::atoi(mp)));
+    autotune_ = !(at && at[0] == '0') && !env_.get("IE_FORCE_TILE") && !env_.get("IE_FORCE_SPLITK") && !env_.get("IE_FORCE_ALGO");
+    if (const char* od = env_.get("IE_TUNE_ON_DEMAND")) tune_on_demand_ = od[0] == '1';
+    if (const char* pc = env_.get("IE_PIPELINE_CHUNKS")) pipeline_chunks_ = std::max(0, std::min(kMaxChunks, std::atoi(pc)));
+    if (const char* ph = env_.get("IE_PIPELINE_HEAD")) pipeline_head_ = std::max(0, std::atoi(ph));
+    if (const char* mp = env_.get("IE_MAX_PLANS")) max_plans_ = size_t(std::max(1, std::atoi(mp)));
     pinned_bytes_ = kPinnedBytes;
     check(hipHostMalloc(&pinned_, pinned_bytes_, hipHostMallocDefault), "hipHostMalloc");
 }
@@ -274,7 +278,7 @@ void DeviceModel::BuildInstance(PlanInstance& pi, const std::vector<std::vector<
                     w_->device_bytes += size_t(aux) * sizeof(float);
                     w_->act_scale.assign(pi.plan.steps.size(), 0.f);
                 }
-            } else if (const char* nf = std::getenv("IE_NO_FRAG_WEIGHTS"); !(nf && std::atoi(nf) != 0)) {
+            } else if (const char* nf = env_.get("IE_NO_FRAG_WEIGHTS"); !(nf && std::atoi(nf) != 0)) {
                 auto add_region = [&](const Step& st) {
                     if (st.kind == StepKind::Conv && st.w_off >= 0 && st.out.c % 16 == 0 && st.in.c % 16 == 0 && st.kh * st.kw <= 49)
                         w_->frag_regions.push_back({st.w_off, int(st.out.c), st.kh * st.kw, int(st.in.c)});
@@ -563,9 +567,9 @@ void DeviceModel::PrepareF8(const std::vector<float>* adopt) {
     if (adopt) W.act_scale = *adopt;
     else {
     int64_t nc = 8;
-    if (const char* e = std::getenv("IE_F8_CALIB_BATCH")) nc = std::max(1, std::min(64, std::atoi(e)));
+    if (const char* e = env_.get("IE_F8_CALIB_BATCH")) nc = std::max(1, std::min(64, std::atoi(e)));
     float margin = 2.0f;
-    if (const char* e = std::getenv("IE_F8_MARGIN")) margin = std::max(1.0f, float(std::atof(e)));
+    if (const char* e = env_.get("IE_F8_MARGIN")) margin = std::max(1.0f, float(std::atof(e)));
     std::vector<std::vector<int64_t>> shapes;
     for (const auto& vi : model_->inputs) {
         std::vector<int64_t> sh = vi.dims;
@@ -768,7 +772,7 @@ void DeviceModel::Autotune(PlanInstance& pi, size_t nsteps, bool allow_search) {
     static const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24};
     constexpr size_t kScrubBytes = size_t(64) << 20;       // > 8 x 4 MiB of L2
     void* scrub = nullptr;
-    if (const char* e = std::getenv("IE_TUNE_HOT"); allow_search && !(e && std::atoi(e) != 0))
+    if (const char* e = env_.get("IE_TUNE_HOT"); allow_search && !(e && std::atoi(e) != 0))
         if (hipMalloc(&scrub, kScrubBytes) != hipSuccess) { scrub = nullptr; (void)hipGetLastError(); }
     bool searched = false;
     try {
@@ -855,7 +859,7 @@ void DeviceModel::Autotune(PlanInstance& pi, size_t nsteps, bool allow_search) {
                         }
                     }
                     choice = best[1] <= best[0] ? 1 : 0;
-                    if (std::getenv("IE_TUNE_LOG")) std::fprintf(stderr, "[tune] dense block %s: chain %.1f us, %zu launches %.1f us\n", s.name.c_str(), best[1] * 1e3, s.parts.size(), best[0] * 1e3);
+                    if (env_.get("IE_TUNE_LOG")) std::fprintf(stderr, "[tune] dense block %s: chain %.1f us, %zu launches %.1f us\n", s.name.c_str(), best[1] * 1e3, s.parts.size(), best[0] * 1e3);
                     std::lock_guard<std::mutex> g(w_->tune_mu);
                     w_->tune_cache[keyb] = {choice, 1};
                     w_->tune_dirty = true;
@@ -1030,7 +1034,7 @@ void DeviceModel::Autotune(PlanInstance& pi, size_t nsteps, bool allow_search) {
             searched = true;
             float best = 1e30f;
             int best_tile = s.tile, best_split = s.splitk;
-            static const bool tune_log = [] { const char* e = std::getenv("IE_TUNE_LOG"); return e && std::atoi(e) != 0; }();
+            const bool tune_log = env_.flag("IE_TUNE_LOG");
             auto time_trial_raw = [&](const Step& trial) {
                 LaunchStep(pi, trial, stream_);              // warm
                 float best_ms = 1e30f;

@@ -21,6 +21,7 @@
 
 #include "kernels.h"
 #include "onnx_reader.h"
+#include "env.h"
 #include "plan.h"
 
 namespace ie {
@@ -158,6 +159,7 @@ public:
     int last_chunks() const { return last_chunks_; }
     int last_head_steps() const { return last_head_steps_; }
     double last_forward_ms() const { return last_forward_ms_; }
+    int max_inflight_replays() const { return max_inflight_replays_; }
 
 private:
     void RunSteps(PlanInstance& pi, size_t first, size_t last, std::vector<hipEvent_t>* events);
@@ -176,6 +178,7 @@ private:
     ConvArgs MakeConvArgs(const PlanInstance& pi, const Step& s) const;
     bool MakeBlockArgs(const PlanInstance& pi, const Step& s, DenseBlockArgs* out) const;   // false: the step is not a well-formed dense-block chain
 
+    Env env_;                            // the lane's switches, read once in the constructor
     std::shared_ptr<const OnnxModel> model_;
     int device_ = 0;
     hipStream_t stream_ = nullptr;       // compute
@@ -207,6 +210,7 @@ private:
     int64_t pipelined_calls_ = 0;
     int last_chunks_ = 1, last_head_steps_ = 0;
     double last_forward_ms_ = 0;
+    int max_inflight_replays_ = 0;      // IE_MAX_INFLIGHT_REPLAYS (0 = unlimited)
 };
 
 // Device queries behind IsCudaAvailable / GetDeviceCount / GetDeviceInfo / GetMemoryInfo

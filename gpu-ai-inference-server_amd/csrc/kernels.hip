@@ -26,6 +26,7 @@
 #include <utility>
 
 #include "igemm_tiles.h"
+#include "env.h"
 #include "kernels.h"
 
 namespace ie {
@@ -575,7 +576,7 @@ static int PersistentSlots(const void* kernel, int block, size_t lds) {
     return cache[{kernel, lds}] = per_cu * cus;
 }
 static int PersistentGrid(int num_tiles, int slots, int splitk) {
-    static const bool off = [] { const char* e = std::getenv("IE_NO_PERSISTENT"); return e && e[0] == '1'; }();
+    const bool off = Knobs().no_persistent;
     if (off) return num_tiles;
     int g = slots / (splitk > 0 ? splitk : 1);
     if (g < 8) g = 8;
@@ -636,7 +637,7 @@ static hipError_t init_igemm_t() {
 hipError_t LaunchConvIgemm(const ConvArgs& a_in, int tile, int vec, int splitk, hipStream_t stream) {
     ConvArgs a = a_in;
     if (a.in.f16) return hipErrorInvalidValue;      // half inputs go through LaunchConvIgemmF16
-    static const int dbg = [] { const char* e = std::getenv("IE_DEBUG_ABLATE"); return e ? std::atoi(e) : 0; }();
+    const int dbg = Knobs().debug_ablate;
     a.debug = dbg;   // timing-only ablations (wrong results): 1 no loads, 2 no MFMA, 4 no LDS stores, 8 no barrier
     if (a.out.sc != 1) return hipErrorInvalidValue;
     // bytes from in.p to one past the last element of the view: the range of the kernel's buffer descriptor

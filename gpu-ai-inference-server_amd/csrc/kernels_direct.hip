@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include "env.h"
 #include "kernels.h"
 
 namespace ie {
@@ -578,7 +579,7 @@ static hipError_t launch_as_t(const ConvArgs& a_in, hipStream_t stream) {
     // every fragment read 2-way conflicted (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.45 in profiles/r01 and r02).  A pad of 8 floats
     // (pitch = 8 or 40 mod 64 for K % 32 == 0) is conflict-free: the counter reads 0 and the LDS-active cycles halve -- at unchanged
     // kernel time (0.610 ms -> 0.610 ms per forward): the kernel was never LDS-bound.
-    static const int pad = [] { const char* e = std::getenv("IE_AS_PAD"); const int v = e ? std::atoi(e) : 8; return (v >= 4 && v <= 68 && v % 4 == 0) ? v : 8; }();
+    const int pad = Knobs().as_pad;
     a.debug = pad << 8;
     const int64_t M = int64_t(a.out.n) * a.out.h * a.out.w;
     const dim3 grid(unsigned((M + 16 * t.pb - 1) / (16 * t.pb)), unsigned(a.out.c / (16 * t.tnw * t.waves)));

@@ -20,6 +20,7 @@
 
 #include <cstdlib>
 
+#include "env.h"
 #include "kernels.h"
 
 namespace ie {
@@ -661,7 +662,7 @@ hipError_t LaunchConvDenseFused(const ConvArgs& a_in, const FusedArgs& f, int ti
         int win_off = 0, poff = 0;
         const size_t ldsw = fused_ws_lds_bytes(a_in, f, pb, &win_off, &poff);
         ConvArgs aw = a_in;
-        static const int dbgw = [] { const char* e = std::getenv("IE_DEBUG_ABLATE"); return e ? std::atoi(e) : 0; }();
+        const int dbgw = Knobs().debug_ablate;
         aw.debug = dbgw;
         if (pb == 1) {
             if (aw.pre_scale) conv_dense_fused_ws_kernel<1, true><<<gridw, dim3(512), ldsw, stream>>>(aw, f, win_off, poff);
@@ -673,7 +674,7 @@ hipError_t LaunchConvDenseFused(const ConvArgs& a_in, const FusedArgs& f, int ti
         return hipGetLastError();
     }
     ConvArgs a = a_in;
-    static const int dbg = [] { const char* e = std::getenv("IE_DEBUG_ABLATE"); return e ? std::atoi(e) : 0; }();
+    const int dbg = Knobs().debug_ablate;
     a.debug = dbg;      // timing-only ablations (wrong results): 1 no 3x3 MFMAs, 2 no 1x1 loop, 4 no 3x3 weight loads, 8 no old-channel loads, 16 no 1x1 weight loads
     const int64_t M = int64_t(a.in.n) * a.in.h * a.in.w;
     const dim3 grid(unsigned((M + 16 * pb - 1) / (16 * pb)));

@@ -11,6 +11,7 @@
 
 #include <cstdlib>
 
+#include "env.h"
 #include "kernels.h"
 
 namespace ie {
@@ -441,7 +442,7 @@ static hipError_t launch_ws32_t(const ConvArgs& a, bool one_per_wave, hipStream_
 hipError_t LaunchConvWs1x1F32(const ConvArgs& a_in, int tile, hipStream_t stream) {
     if (!ConvWs32Eligible(a_in, tile)) return hipErrorInvalidValue;
     ConvArgs a = a_in;
-    static const int dbg = [] { const char* e = std::getenv("IE_DEBUG_ABLATE"); return e ? std::atoi(e) : 0; }();
+    const int dbg = Knobs().debug_ablate;
     a.debug = dbg;                                     // timing-only ablations (wrong results): 32 no stores, 64 no MFMAs, 128 no weight preamble
     a.in_bytes = 4 * (int64_t(a.in.n - 1) * a.in.sn + int64_t(a.in.h - 1) * a.in.sh + int64_t(a.in.w - 1) * a.in.sw + int64_t(a.in.c - 1) + 1);
     if (tile == kNumConvWsTiles) return a.pre_scale ? launch_wsk32_t<8, true>(a, stream) : launch_wsk32_t<8, false>(a, stream);

@@ -8,13 +8,16 @@
 #include <sstream>
 #include <stdexcept>
 
+#include "env.h"
 #include "igemm_tiles.h"
 
 namespace ie {
 
 // Dense-layer fusion applies where launches are latency-bound: up to this many output pixels (IE_FUSE_MAX_M overrides; A/B switch).
-static int64_t FuseMaxPixels() {
-    static const int64_t v = [] { const char* e = std::getenv("IE_FUSE_MAX_M"); const long long x = e ? std::atoll(e) : 0; return x > 0 ? int64_t(x) : int64_t(8192); }();
+static int64_t FuseMaxPixels(const Env& env) {
+    const char* e = env.get("IE_FUSE_MAX_M");
+    const long long x = e ? std::atoll(e) : 0;
+    const int64_t v = x > 0 ? int64_t(x) : int64_t(8192);
     return v;
 }
 namespace {
@@ -211,6 +214,7 @@ ModelInfo DescribeModel(const OnnxModel& m) {
 }
 
 Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& input_shapes, Precision precision, bool f8_fusions) {
+    const Env env = Env::Read();          // the planner's switches, read once per plan build (load / prepare time)
     Lowering L(m);
     Plan plan;
     plan.precision = precision;
@@ -579,7 +583,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
     // constant).  DenseNet's transitions (BN -> ReLU -> Conv1x1 -> AvgPool2x2) then run their conv on a quarter of the pixels:
     // 4x fewer FLOPs for those layers (8 % of the network), and the BN+ReLU prologue rides on the pool.  Only when the pool window
     // tiles the image exactly (no padding, no partial windows), so every output averages the same number of inputs.
-    if (!std::getenv("IE_NO_POOL_SWAP")) {
+    if (!env.get("IE_NO_POOL_SWAP")) {
         for (size_t i = 0; i < L.nodes.size(); ++i) {
             if (L.nodes[i].dead || L.nodes[i].kind != L_CONV) continue;
             const LNode& cv0 = L.nodes[i];
@@ -759,7 +763,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
     // Dense fusion (see the pass after step emission): when a 3x3 conv and the 1x1 conv behind it will run as ONE launch, the 3x3's
     // input (the bottleneck tensor, read as halo by neighbouring tiles) must outlive the launch that also writes the next
     // bottleneck: keep it live one position longer so the two never share a buffer.
-    if (precision == Precision::F32 && !std::getenv("IE_NO_DENSE_FUSE"))
+    if (precision == Precision::F32 && !env.get("IE_NO_DENSE_FUSE"))
         for (size_t pos = 0; pos + 1 < order.size(); ++pos) {
             const LNode& a3 = L.nodes[order[pos]];
             size_t nxt = pos + 1;                      // Concat / alias nodes emit nothing: the launch behind the 3x3 is the next real node
@@ -768,7 +772,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
             const LNode& b1 = L.nodes[order[nxt]];
             if (a3.kind != L_CONV || b1.kind != L_CONV || a3.kh != 3 || a3.kw != 3 || b1.kh != 1 || b1.kw != 1 || a3.has_pre) continue;
             if (L.vals[a3.out].c != 32 || L.vals[b1.out].c != 128 || L.vals[b1.in[0]].root != L.vals[a3.out].root) continue;
-            if (L.vals[a3.out].n * L.vals[a3.out].h * L.vals[a3.out].w > FuseMaxPixels()) continue;
+            if (L.vals[a3.out].n * L.vals[a3.out].h * L.vals[a3.out].w > FuseMaxPixels(env)) continue;
             const int rb = L.vals[a3.in[0]].root;
             last_use[rb] = std::max(last_use[rb], int(nxt));
         }
@@ -991,7 +995,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                 // ---- default choice without the autotuner (IE_AUTOTUNE=0, or before Prepare() has timed anything): the kernels
                 //      the exhaustive search picks for DenseNet / ResNet shapes ----
                 if (s.algo == ConvAlgo::IgemmF8) {
-                    if (const char* ft = std::getenv("IE_FORCE_TILE")) {
+                    if (const char* ft = env.get("IE_FORCE_TILE")) {
                         const int t = std::atoi(ft);
                         if (t >= 0 && t < kNumIgemmBaseTiles && !(kIgemmTiles[t].bn > 32 && N <= 32)) s.tile = t;
                         // >= 100: the weights-stationary 1x1 kernel's tiles, >= 200: the 3x3's (kernels_ws8.hip); a launcher that declines the
@@ -1001,7 +1005,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                     }
                     break;
                 }
-                if (!std::getenv("IE_FORCE_ALGO") && !std::getenv("IE_FORCE_TILE") && s.algo == ConvAlgo::IgemmVec) {
+                if (!env.get("IE_FORCE_ALGO") && !env.get("IE_FORCE_TILE") && s.algo == ConvAlgo::IgemmVec) {
                     int pick = -1;
                     if (M <= 2048) {                                                       // tiny grids: split K over the waves
                         if (is3x3 && direct_ok(6)) pick = 6;                             // 16-pixel window tiles: 4x the workgroups
@@ -1020,7 +1024,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                     }
                 }
                 // Test / tuning overrides (read at plan time): IE_FORCE_TILE=<n>, IE_FORCE_ALGO=naive|scalar|igemm|raster|ws|direct
-                if (const char* fa = std::getenv("IE_FORCE_ALGO")) {
+                if (const char* fa = env.get("IE_FORCE_ALGO")) {
                     std::string f = fa;
                     if (f == "naive") s.algo = ConvAlgo::Naive;
                     else if (f == "scalar" && K <= 2048 && !in16) s.algo = ConvAlgo::IgemmScalar;
@@ -1029,14 +1033,14 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                         s.algo = (vec_ok || vec16_ok) ? ConvAlgo::IgemmVec : (K <= 2048 && !in16 ? ConvAlgo::IgemmScalar : ConvAlgo::Naive);
                     else if (f == "ws") {
                         int t = 0;
-                        if (const char* ft = std::getenv("IE_FORCE_TILE")) { int v = std::atoi(ft); if (v >= 0 && v < (in16 ? 12 : 14)) t = v; }
+                        if (const char* ft = env.get("IE_FORCE_TILE")) { int v = std::atoi(ft); if (v >= 0 && v < (in16 ? 12 : 14)) t = v; }
                         if (ws16_ok(t) || ws32_ok(t)) { s.algo = ConvAlgo::Ws1x1; s.tile = t; }
                         else if (ws3_ok(t % 4)) { s.algo = ConvAlgo::Ws3x3; s.tile = t % 4; }
                         else if (s.algo == ConvAlgo::Naive && vec16_ok) s.algo = ConvAlgo::IgemmVec;
                     }
                     else if (f == "direct") {
                         int t = 0;
-                        if (const char* ft = std::getenv("IE_FORCE_TILE")) { int v = std::atoi(ft); if (v >= 0 && v < 15) t = v; }
+                        if (const char* ft = env.get("IE_FORCE_TILE")) { int v = std::atoi(ft); if (v >= 0 && v < 15) t = v; }
                         if (direct_ok(t)) { s.algo = ConvAlgo::Direct; s.tile = t; }
                         else if (s.algo == ConvAlgo::Naive && (vec_ok || vec16_ok)) s.algo = ConvAlgo::IgemmVec;
                     }
@@ -1045,14 +1049,14 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                         if (x6_ok) {
                             s.algo = ConvAlgo::X6;
                             s.tile = 0;
-                            if (const char* ft = std::getenv("IE_FORCE_TILE")) { int t = std::atoi(ft); if (t >= 0 && t < 2) s.tile = t; }
+                            if (const char* ft = env.get("IE_FORCE_TILE")) { int t = std::atoi(ft); if (t >= 0 && t < 2) s.tile = t; }
                         }
                     }
                     else if (f == "wino") {
                         if (wino_ok) {
                             s.algo = ConvAlgo::Wino3x3;
                             s.tile = 0;
-                            if (const char* ft = std::getenv("IE_FORCE_TILE")) { int t = std::atoi(ft); if (t >= 0 && t < 12) s.tile = t; }
+                            if (const char* ft = env.get("IE_FORCE_TILE")) { int t = std::atoi(ft); if (t >= 0 && t < 12) s.tile = t; }
                         } else if (s.algo == ConvAlgo::Naive)
                             s.algo = (vec_ok || vec16_ok) ? ConvAlgo::IgemmVec : (K <= 2048 && !in16 ? ConvAlgo::IgemmScalar : ConvAlgo::Naive);
                     }
@@ -1060,20 +1064,20 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                         if (raster_ok) {
                             s.algo = ConvAlgo::Raster3x3;
                             s.tile = 0;
-                            if (const char* ft = std::getenv("IE_FORCE_TILE")) { int t = std::atoi(ft); if (t >= 0 && t < 8) s.tile = t; }
+                            if (const char* ft = env.get("IE_FORCE_TILE")) { int t = std::atoi(ft); if (t >= 0 && t < 8) s.tile = t; }
                         } else if (s.algo == ConvAlgo::Naive)
                             s.algo = (vec_ok || vec16_ok) ? ConvAlgo::IgemmVec : (K <= 2048 && !in16 ? ConvAlgo::IgemmScalar : ConvAlgo::Naive);
                     }
                 }
                 if (const char* ft = (s.algo == ConvAlgo::Raster3x3 || s.algo == ConvAlgo::Ws1x1 || s.algo == ConvAlgo::Ws3x3 || s.algo == ConvAlgo::Stem || s.algo == ConvAlgo::Direct || s.algo == ConvAlgo::Wino3x3 || s.algo == ConvAlgo::X6) ? nullptr
-                                                                                                                                          : std::getenv("IE_FORCE_TILE")) {
+                                                                                                                                          : env.get("IE_FORCE_TILE")) {
                     int t = std::atoi(ft);
                     if (t >= 0 && t < kNumIgemmTiles && (t < kNumIgemmBaseTiles || s.algo == ConvAlgo::IgemmVec) && !(in16 && kIgemmTiles[t].deep)) s.tile = t;
                 }
                 if (s.algo != ConvAlgo::IgemmVec && s.algo != ConvAlgo::Raster3x3 && s.algo != ConvAlgo::Ws1x1 && s.algo != ConvAlgo::Ws3x3 && s.algo != ConvAlgo::Direct && s.algo != ConvAlgo::Wino3x3 && s.algo != ConvAlgo::X6 && s.tile >= kNumIgemmBaseTiles)
                     s.tile = heuristic_tile;       // K-group tiles exist for the vector path only
                 if (s.algo == ConvAlgo::Raster3x3) {
-                    if (const char* fs = std::getenv("IE_FORCE_SPLITK")) {
+                    if (const char* fs = env.get("IE_FORCE_SPLITK")) {
                         int v = std::atoi(fs);
                         if (v >= 1 && v <= 64) s.splitk = v;
                     }
@@ -1091,7 +1095,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                         int64_t want = (768 + wgs - 1) / wgs;
                         s.splitk = int(std::max<int64_t>(1, std::min<int64_t>({want, KT / 2, 32})));
                     }
-                    if (const char* fs = std::getenv("IE_FORCE_SPLITK")) {
+                    if (const char* fs = env.get("IE_FORCE_SPLITK")) {
                         int v = std::atoi(fs);
                         if (v >= 1 && v <= 64) s.splitk = v;
                     }
@@ -1160,7 +1164,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
     // Pattern: step i = plain 3x3/s1/p1 conv (no prologue, 32 output channels) writing a channel slice of a concat buffer; step i+1 =
     // 1x1 conv with 128 output channels whose input view is that buffer's channels [c_off, slice end): its last 32 input channels are
     // exactly what step i produces, for the same pixels (kernels_fused.hip).  Only where launches are latency-bound (M <= 8192).
-    if (precision == Precision::F32 && !std::getenv("IE_NO_DENSE_FUSE") && !std::getenv("IE_FORCE_ALGO") && !std::getenv("IE_FORCE_TILE")) {
+    if (precision == Precision::F32 && !env.get("IE_NO_DENSE_FUSE") && !env.get("IE_FORCE_ALGO") && !env.get("IE_FORCE_TILE")) {
         std::vector<Step> fusedsteps;
         for (size_t i = 0; i < plan.steps.size(); ++i) {
             const Step& s3 = plan.steps[i];
@@ -1173,12 +1177,12 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                        9 * (s3.in.c / 16) >= 8 && s1.kh == 1 && s1.kw == 1 && s1.sh == 1 && s1.sw == 1 && s1.pt == 0 && s1.pl == 0 && s1.pb == 0 && s1.pr == 0 &&
                        !s1.has_in2 && s1.out.c == 128 && s1.in.buf == s3.out.buf && s1.in.pitch == s3.out.pitch && !s1.in.nchw && !s3.in.nchw &&
                        s1.in.c_off + s1.in.c == s3.out.c_off + s3.out.c && s1.in.c >= 48 && s1.in.c % 16 == 0 && s1.in.n == s3.out.n && s1.in.h == s3.out.h &&
-                       s1.in.w == s3.out.w && s1.out.buf != s3.in.buf && M <= FuseMaxPixels() && s3.algo != ConvAlgo::Naive && s1.algo != ConvAlgo::Naive &&
+                       s1.in.w == s3.out.w && s1.out.buf != s3.in.buf && M <= FuseMaxPixels(env) && s3.algo != ConvAlgo::Naive && s1.algo != ConvAlgo::Naive &&
                        s3.in.pitch % 4 == 0 && s3.in.c_off % 4 == 0 && s1.in.pitch % 4 == 0 && s1.in.c_off % 4 == 0 && s1.out.pitch % 4 == 0 && s1.out.c_off % 4 == 0;
                 if (fuse) {
                     int pb = M <= 2048 ? 1 : 2;
                     int ftile = 0;
-                    if (const char* e = std::getenv("IE_FUSE_PB")) { const int v = std::atoi(e); if (v == 1 || v == 2) pb = v; if (v == 3) { pb = 1; ftile = 3; } if (v == 4 || v == 5) { pb = v - 3; ftile = v; } }
+                    if (const char* e = env.get("IE_FUSE_PB")) { const int v = std::atoi(e); if (v == 1 || v == 2) pb = v; if (v == 3) { pb = 1; ftile = 3; } if (v == 4 || v == 5) { pb = v - 3; ftile = v; } }
                     const int64_t px = 16 * pb;
                     const int64_t win = (px + 2 * s3.in.w + 2) * (s3.in.c + 8) * 4, part = 4 * px * 36 * 4;
                     const int64_t c4n = (s1.in.c - 32) / 4, rpp = c4n > 0 && c4n <= 512 ? 512 / c4n : 0;
@@ -1223,7 +1227,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
     // tensor T, step i+1 = plain 3x3/s1/p1 conv (no prologue, no residual) from T to 32 channels of the SAME concat buffer outside what the
     // layer reads, T read by nothing else.  A layer touches only its own image, so a workgroup per image walks the whole chain with T in LDS
     // (kernels_block.hip): DenseNet-121 blocks 3-4 at batch 128 go from 80 launches to 2.  Maps of at most 8 x 32 raster positions (14x14, 7x7).
-    if (precision == Precision::F16 && !std::getenv("IE_NO_DENSE_BLOCK") && !std::getenv("IE_FORCE_ALGO") && !std::getenv("IE_FORCE_TILE")) {
+    if (precision == Precision::F16 && !env.get("IE_NO_DENSE_BLOCK") && !env.get("IE_FORCE_ALGO") && !env.get("IE_FORCE_TILE")) {
         auto same_view = [](const View& a, const View& b) {
             return a.buf == b.buf && a.n == b.n && a.c == b.c && a.h == b.h && a.w == b.w && a.c_off == b.c_off && a.pitch == b.pitch && a.nchw == b.nchw && a.f16 == b.f16;
         };
@@ -1275,7 +1279,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
             // (28x28: 39-58 vs 42-54 us per layer; 56x56: 160-218 vs 93-123 us: the per-band fixed cost -- 72 KB of 3x3 weights into LDS, raster
             // reset, epilogue -- is paid 5 ... 28 times per image): the parts are the default there, the search may still pick the launch
             f.tile = (plan.steps[i].in.h * (plan.steps[i].in.w + 1) + 31) / 32 > 7 ? 0 : 1;
-            if (const char* e = std::getenv("IE_DENSE_BAND"); e && std::atoi(e) != 0) f.tile = 1;       // tests: band mode on by default
+            if (const char* e = env.get("IE_DENSE_BAND"); e && std::atoi(e) != 0) f.tile = 1;       // tests: band mode on by default
             f.splitk = 1;
             f.flops = 0;
             f.bytes = 0;
@@ -1312,7 +1316,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
     // residual, no ReLU) read by nothing else.  out = relu(C(a) + P(x)) then runs as two accumulator sets of one launch (kernels_ws8.hip) and
     // P's output -- the largest tensor of the block -- is never written.  P moves down to C's position (everything between them is independent
     // of P's output: its only reader is C).
-    if ((precision == Precision::F8 || f8_fusions) && !std::getenv("IE_NO_DUAL_F8")) {
+    if ((precision == Precision::F8 || f8_fusions) && !env.get("IE_NO_DUAL_F8")) {
         for (size_t j = 0; j < plan.steps.size(); ++j) {
             Step& c = plan.steps[j];
             if (c.kind != StepKind::Conv || !c.has_in2 || !c.parts.empty() || c.kh != 1 || c.kw != 1 || c.sh != 1 || c.sw != 1 || c.pt || c.pl || c.pb || c.pr) continue;

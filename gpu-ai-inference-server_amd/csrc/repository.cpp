@@ -1,4 +1,5 @@
 #include "repository.h"
+#include "env.h"
 
 #include <algorithm>
 #include <cctype>
@@ -49,7 +50,8 @@ bool Repository::Scan() {
             // (server/main.go:640-655: sort.Strings over isNumeric names), e.g. "2" over "10", while the reference's C++ side -- and
             // this engine by default -- loads the numerically latest (model_repository.cpp:45-53).  With versions >= 10 the two
             // disagree about which version "latest" is; this switch makes the engine follow the Go side's rule.
-            const char* ord = std::getenv("IE_VERSION_ORDER");
+            const Env env = Env::Read();
+            const char* ord = env.get("IE_VERSION_ORDER");
             if (ord && (std::strcmp(ord, "go") == 0 || std::strcmp(ord, "lexicographic") == 0)) {
                 std::stable_sort(vs.begin(), vs.end(), [](const std::string& a, const std::string& b) {
                     auto digits = [](const std::string& v) { return !v.empty() && std::all_of(v.begin(), v.end(), [](unsigned char c) { return std::isdigit(c) != 0; }); };
