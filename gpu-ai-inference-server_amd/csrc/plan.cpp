@@ -1247,8 +1247,11 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
             if ((s1.pre_scale_off >= 0) != (s1.pre_shift_off >= 0)) return false;
             // up to 7 raster tiles: a workgroup per image (chains of layers); larger maps: bands of rows, one layer per launch, while at least one
             // row + halo fits the 8 staged tiles
+            // Band mode measured no faster than the two streaming kernels at batch 128 (28x28: 39-58 vs 42-54 us per layer; 56x56: 160-218 vs 93-123 us:
+            // the per-band fixed cost -- 72 KB of 3x3 weights into LDS, raster reset, epilogue -- is paid 5 ... 28 times per image), so such steps are
+            // only formed on request (IE_DENSE_BAND=1: tests, experiments).
             const int64_t ntiles = (s1.in.h * (s1.in.w + 1) + 31) / 32;
-            if (ntiles > 7 && 256 / (s1.in.w + 1) < 3) return false;
+            if (ntiles > 7 && (!env.flag("IE_DENSE_BAND") || 256 / (s1.in.w + 1) < 3)) return false;
             // T must have no other reader: the fused kernel never writes it to memory
             for (size_t j = i + 2; j < plan.steps.size(); ++j) {
                 const Step& q = plan.steps[j];
@@ -1275,11 +1278,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
             if (n == 0) { blocksteps.push_back(plan.steps[i]); ++i; continue; }
             Step f = plan.steps[i];
             f.algo = ConvAlgo::DenseBlock;
-            // band mode (maps of more than 7 raster tiles, one layer per launch) measured no faster than the two streaming kernels at batch 128
-            // (28x28: 39-58 vs 42-54 us per layer; 56x56: 160-218 vs 93-123 us: the per-band fixed cost -- 72 KB of 3x3 weights into LDS, raster
-            // reset, epilogue -- is paid 5 ... 28 times per image): the parts are the default there, the search may still pick the launch
-            f.tile = (plan.steps[i].in.h * (plan.steps[i].in.w + 1) + 31) / 32 > 7 ? 0 : 1;
-            if (const char* e = env.get("IE_DENSE_BAND"); e && std::atoi(e) != 0) f.tile = 1;       // tests: band mode on by default
+            f.tile = 1;
             f.splitk = 1;
             f.flops = 0;
             f.bytes = 0;

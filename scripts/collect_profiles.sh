@@ -1,17 +1,19 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun): bench + rocprofv3 kernel trace + separate PMC passes -> gpurun_out/<round>/
 #   fp32 batch 32 DenseNet-121 (the headline, BASELINE configs[1]), fp16 batch 128 (configs[2]), ResNet-50 fp8 batch 256 (configs[4]).
-#   plus the opt-in fp32 + bf16x6 configuration (batch 32).  PMC passes never combine with tracing domains.  Traced / counted runs launch
-#   the plan's kernels eagerly (same kernels, same durations): hipGraphLaunch under rocprofv3 segfaults intermittently on this ROCm
-#   (profiles/r02/graph_burst_under_kernel_trace_sigsegv.log); IE_PROFILE_GRAPH=1 traces the graph replays instead.
+#   plus the opt-in fp32 + bf16x6 configuration (batch 32).  PMC passes never combine with tracing domains.  Since round 3 the traced / counted
+#   runs are the SAME program bench.py times: hipGraph replays, with the in-flight depth capped (IE_MAX_INFLIGHT_REPLAYS=8: the engine
+#   synchronises every 8 replays) -- deep un-synchronised graph queues under rocprofv3 --kernel-trace segfaulted inside hipGraphLaunch
+#   (profiles/r02/graph_burst_under_kernel_trace_sigsegv.log; single synchronised launches always traced fine).  IE_PROFILE_EAGER=1 goes
+#   back to eager launches of the plan's kernels.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/${1:-r02}
+OUT=$R/gpurun_out/${1:-r03}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export IE_TUNE_CACHE=$OUT/tune_cache.txt
-TRACE_ENV="IE_DISABLE_GRAPH=1"
-[ -n "$IE_PROFILE_GRAPH" ] && TRACE_ENV="IE_DISABLE_GRAPH=0"
+TRACE_ENV="IE_DISABLE_GRAPH=0 IE_MAX_INFLIGHT_REPLAYS=8"
+[ -n "$IE_PROFILE_EAGER" ] && TRACE_ENV="IE_DISABLE_GRAPH=1"
 ROUND=$(basename $OUT)
 python3 $R/scripts/profile_steps.py 32 > $OUT/steps_b32.txt 2>&1
 IE_PRECISION=fp16 python3 $R/scripts/profile_steps.py 128 > $OUT/steps_f16_b128.txt 2>&1
