@@ -137,15 +137,26 @@ struct Parser {
     }
 };
 
+// Numbers are doubles in JSON: a value outside the target integer's range (1e30, NaN) would be undefined behaviour in the cast; it is
+// clamped to +-2^31 (dims, batch sizes and counts are small; the callers clamp further to what they accept).
+int64_t clamp_ll(double x) {
+    if (!(x == x)) return 0;
+    const double lim = 2147483648.0;
+    return int64_t(std::llround(x > lim ? lim : (x < -lim ? -lim : x)));
+}
 std::vector<int64_t> int_list(const JsonValue* v) {
     std::vector<int64_t> out;
     if (v && v->type == JsonValue::Array)
         for (const auto& e : v->arr)
-            if (e.type == JsonValue::Number) out.push_back(int64_t(std::llround(e.num)));
+            if (e.type == JsonValue::Number && out.size() < 64) out.push_back(clamp_ll(e.num));
     return out;
 }
 std::string str_of(const JsonValue* v) { return v && v->type == JsonValue::String ? v->str : std::string(); }
-int int_of(const JsonValue* v, int def) { return v && v->type == JsonValue::Number ? int(std::llround(v->num)) : def; }
+int int_of(const JsonValue* v, int def) {
+    if (!v || v->type != JsonValue::Number) return def;
+    const int64_t x = clamp_ll(v->num);
+    return int(x > 2147483647 ? 2147483647 : x);
+}
 
 std::vector<IoConfig> io_list(const JsonValue* v) {
     std::vector<IoConfig> out;

@@ -172,6 +172,10 @@ def test_config_json_is_parsed_not_scraped(tmp_path):
     c2 = B.DescribeModel(path2)["config"]
     assert (c2["gpus"], c2["precision"], c2["dynamic_batching"], c2["max_batch_size"], c2["batch_window_us"]) == (4, "fp16", True, 16, 50)
     assert c2["fp32_split"] is True
+    # numbers far outside the integer range are clamped, never cast blindly: 1e30 -> 2^31 - 1 for counts, 2^31 in lists
+    path4 = models.write_repo(str(tmp_path), "huge", models.gemm_mlp("N"), config_json='{"gpus": 1e30, "instance_count": -1e30, "max_batch_size": 1e300, "tune_batches": [1e30, 4, -1e30]}')
+    c4 = B.DescribeModel(path4)["config"]
+    assert c4["gpus"] == 2147483647 and c4["instance_count"] == -2147483648 and c4["max_batch_size"] == 2147483647 and c4["tune_batches"] == [2147483648, 4, -2147483648]
     # no file: defaults; malformed file: an error that names the position, not a silent default
     path3 = models.write_repo(str(tmp_path), "nocfg", models.gemm_mlp("N"))
     assert B.DescribeModel(path3)["config"]["present"] is False
