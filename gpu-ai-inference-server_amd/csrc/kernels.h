@@ -170,7 +170,8 @@ struct DenseBlockArgs {
     uint64_t w16_bytes = 0;            // size of each of the two half blobs (buffer descriptors: < 2 GiB)
     const float* w32 = nullptr;
     int nlayers = 0;
-    int band_rows = 0;                 // set by the launcher: 0 = a workgroup per image, else image rows per workgroup (band mode, one layer)
+    int band_rows = 0;                 // set by the launcher: 0 = a workgroup per image, else image rows per workgroup (band mode) / per step (strip mode)
+    int strip_rows = 0;                // set by the launcher: > 0 = strip mode: image rows per workgroup, walked in steps of band_rows
     long long* dbg = nullptr;          // probes only: per-phase cycle sums of workgroup 0 / wave 0 (1x1 loop, weight DMA + 1x1 epilogue, 3x3, closing barrier)
     DenseBlockLayer layer[kMaxBlockLayers];
 };

@@ -432,25 +432,340 @@ __global__ __launch_bounds__(512) void dense_block_f16_kernel(const DenseBlockAr
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// Strip mode: ONE dense layer on maps too large for a workgroup per image (DenseNet-121 blocks 1-2: 56x56, 28x28), without the bottleneck
+// tensor's round trip through memory (61 % of those layers' bytes) and without the per-band fixed cost that sank band mode.  A workgroup owns a
+// STRIP of image rows and slides down it: every step stages R new rows of the image (R x (W + 1) raster positions = TMS tiles), runs the 1x1 over
+// their K channels (chunks through LDS, producer / consumer waves as in the chain kernel), writes the new bottleneck rows into a RING of R + 2
+// raster rows in LDS, and runs the 3x3 for the R rows whose three input rows are now complete.  The 72 KB of 3x3 weights are loaded ONCE per
+// workgroup and stay in LDS (their own region, beside the ring and the chunk staging); the 1x1 weights are re-streamed from L2 every step straight
+// into the consumers' register rings.  The producers run one chunk ahead across step boundaries (chunk 0 of step s + 1 is staged while the
+// consumers finish step s), so the phases form one stream with one barrier each: NC chunks + one 3x3 phase per step.
+// A ring row's pad column and the guard row in front of the ring stay zero for the whole launch; a ring row that stands for a row outside the
+// image is written with zeros (the ring slots are reused, unlike the chain kernel's raster).
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+template <int TMS>
+__global__ __launch_bounds__(512) void dense_strip_f16_kernel(const DenseBlockArgs a) {
+    constexpr int PITS = TMS;                              // 16-byte pieces per producer thread and chunk (rows tp / 8 + 32 i)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_blk[];
+    const int H = a.h, W = a.w, PW = W + 1;
+    const int R = a.band_rows, NR = R + 2, SRows = a.strip_rows;
+    const int nstrips = (H + SRows - 1) / SRows;
+    const int img = int(blockIdx.x) / nstrips;
+    const int ya = (int(blockIdx.x) - img * nstrips) * SRows;
+    const int yb = ya + SRows < H ? ya + SRows : H;
+    const int ys0 = ya - 1;                                // image row of the first staged row
+    const int nsteps = (yb - ya + 2 + R - 1) / R;          // rows ya - 1 .. yb are staged
+    const int NPs = R * PW;                                // raster positions per step
+    _Float16* const sW3 = reinterpret_cast<_Float16*>(smem_blk);                             // all 3x3 weights, fragment-major (72 KB)
+    _Float16* const sT = sW3 + kW3Bytes / 2;                                                 // [1 + NR * PW + 1][kTPitch]: guard row, ring, guard row
+    const int trows = NR * PW + 2;
+    _Float16* const sA0 = sT + size_t(trows) * kTPitch;
+    _Float16* const sA1 = sA0 + size_t(32 * TMS) * kAPitch;
+    float* const sBias = reinterpret_cast<float*>(sA1 + size_t(32 * TMS) * kAPitch);         // [128] 1x1 bias, [32] 3x3 bias
+    _Float16* const sPre = reinterpret_cast<_Float16*>(sBias + 160);                         // [2][kMaxK] prologue scale, shift
+
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pitch = a.pitch;
+    _Float16* const ximg = a.x + size_t(img) * H * W * pitch;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(ximg, 0, H * W * pitch * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wf = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.wfrag16), 0, int(a.w16_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w16 = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.w16), 0, int(a.w16_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w32 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w32), 0, int(a.w16_bytes * 2 < 0x7fffffffull ? a.w16_bytes * 2 : 0x7fffffffull), 0x00020000);
+    const DenseBlockLayer& L = a.layer[0];
+    const int K = L.K, NC = (K + 63) >> 6;
+    const int G = nsteps * NC;                             // chunks of the whole strip, as one stream
+
+    {       // ring, pad columns and guard rows start at zero
+        const int n16 = trows * kTPitch / 8;
+        for (int q = tid; q < n16; q += 512) reinterpret_cast<u32x4*>(sT)[q] = u32x4{0u, 0u, 0u, 0u};
+    }
+
+    if (wave >= 4) {
+        // =========================================== PRODUCERS ===========================================
+        const int tp = tid - 256;
+        const int c8 = (tp & 7) * 8;
+        int pry[PITS], px[PITS];       // the thread's positions inside a step: row of the step, column (pad column / past the step: px = -1)
+#pragma unroll
+        for (int i = 0; i < PITS; ++i) {
+            const int p = (tp >> 3) + 32 * i;
+            const int y = p / PW, x = p - y * PW;
+            pry[i] = y;
+            px[i] = (p < NPs && x < W) ? x : -1;
+        }
+        struct ASlot { u32x4 v[PITS]; };
+        ASlot ra[3];
+        auto issue = [&](ASlot& A, int g) {                // chunk g of the stream = (step g / NC, chunk g % NC); past the strip: zeros, no traffic
+            const int st = g / NC, c = g - st * NC;
+            const bool cok = g < G && c * 64 + c8 < K;
+            const int ybase = ys0 + st * R;
+#pragma unroll
+            for (int i = 0; i < PITS; ++i) {
+                const int y = ybase + pry[i];
+                const bool ok = cok && px[i] >= 0 && y >= 0 && y < H;
+                A.v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? unsigned((y * W + px[i]) * pitch + a.in_coff + c * 64 + c8) * 2u : kOOB, 0, 0);
+            }
+        };
+        auto commit = [&](const ASlot& A, int g) {
+            _Float16* const dst = (g & 1) ? sA1 : sA0;
+            const int c = g % NC;
+            const int cb = c * 64 + c8 < K ? c * 64 + c8 : 0;
+            const h8 s8 = *reinterpret_cast<const h8*>(sPre + cb), t8 = *reinterpret_cast<const h8*>(sPre + kMaxK + cb);
+            const _Float16 lo = (L.flags & 1) ? _Float16(0.f) : _Float16(-65504.f);
+            const h8 lo8 = {lo, lo, lo, lo, lo, lo, lo, lo};
+#pragma unroll
+            for (int i = 0; i < PITS; ++i) {
+                const int l = (tp >> 3) + 32 * i;
+                h8 v = __builtin_bit_cast(h8, A.v[i]) * s8 + t8;
+                v = pk_max8(v, lo8);
+                *reinterpret_cast<h8*>(dst + l * kAPitch + c8) = v;
+            }
+        };
+        // ---- once per workgroup: constants and the 3x3 weights -> LDS ----
+        {
+            u32x4 cpre[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = tp + 256 * j, half = q * 8 < K ? 0 : 1, off = q * 8 - half * K;
+                const bool ok = L.ps != 0xffffffffu && off < K;
+                cpre[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w16, ok ? ((half ? L.pt : L.ps) + unsigned(off)) * 2u : kOOB, 0, 0);
+            }
+            const unsigned bo = tp < 128 ? L.b1 : L.b3;
+            const float cbias = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_w32, (tp < 160 && bo != 0xffffffffu) ? (bo + unsigned(tp < 128 ? tp : tp - 128)) * 4u : kOOB, 0, 0));
+            u32x4 w3r[18];
+#pragma unroll
+            for (int q = 0; q < 18; ++q) w3r[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_wf, (L.w3 + unsigned(q * 256 + tp) * 8u) * 2u, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = tp + 256 * j, half = q * 8 < K ? 0 : 1, off = q * 8 - half * K;
+                if (off < K) {
+                    const u32x4 ident = half ? u32x4{0u, 0u, 0u, 0u} : u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+                    *reinterpret_cast<u32x4*>(sPre + half * kMaxK + off) = L.ps != 0xffffffffu ? cpre[j] : ident;
+                }
+            }
+            if (tp < 160) sBias[tp] = cbias;
+#pragma unroll
+            for (int q = 0; q < 18; ++q) *reinterpret_cast<u32x4*>(sW3 + (q * 256 + tp) * 8) = w3r[q];
+        }
+        issue(ra[0], 0);
+        issue(ra[1], 1);
+        issue(ra[2], 2);
+        __syncthreads();                                   // constants, 3x3 weights and the zeroed ring in place
+        commit(ra[0], 0);
+        issue(ra[0], 3);
+        __syncthreads();                                   // chunk 0 staged
+        // chunk g (slot g % 3) is committed while the consumers compute chunk g - 1; behind the last chunk of a step comes their 3x3 phase
+        auto step = [&](ASlot& A, int g) {
+            commit(A, g);                                  // (g == G: zeros into a buffer nobody reads)
+            issue(A, g + 3);
+            __syncthreads();
+            if ((g - 1) % NC == NC - 1) __syncthreads();   // the consumers' 3x3 phase
+        };
+        int g = 1;
+        for (; g + 3 <= G + 1; g += 3) {
+            step(ra[1], g);
+            step(ra[2], g + 1);
+            step(ra[0], g + 2);
+        }
+        if (g <= G) { step(ra[1], g); ++g; }
+        if (g <= G) { step(ra[2], g); ++g; }
+    } else {
+        // =========================================== CONSUMERS ===========================================
+        const int np = wave;
+        int pry[TMS], px[TMS];         // per tile: the lane's row inside a step and column (-1: pad column / past the step)
+#pragma unroll
+        for (int i = 0; i < TMS; ++i) {
+            const int p = i * 32 + r;
+            const int y = p / PW, x = p - y * PW;
+            pry[i] = y;
+            px[i] = (p < NPs && x < W) ? x : -1;
+        }
+        // the 3x3's tile of this wave (tile = wave): static selects, a runtime index into the per-tile arrays would send them to scratch
+        int my_ry = pry[0], my_x = px[0];
+#pragma unroll
+        for (int i = 1; i < TMS; ++i)
+            if (wave == i) { my_ry = pry[i]; my_x = px[i]; }
+        struct BSlot { u32x4 f[4]; };
+        BSlot bs[3];
+        auto issue_b = [&](BSlot& Bq, int g) {             // the 1x1 weights of chunk g % NC (the same bytes every step: L2)
+            const int c = g % NC;
+            const int nks = g < G ? (K - c * 64) >> 4 : 0;
+            const unsigned base = (L.w1 + (unsigned(c) * 16u + unsigned(np)) * 512u + unsigned(lane) * 8u) * 2u;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) Bq.f[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_wf, s < nks ? base + unsigned(s) * 4096u : kOOB, 0, 0);
+        };
+        f32x16 acc[TMS];
+        auto compute1 = [&](const BSlot& Bq, int g) {
+            constexpr int NST = 4 * TMS, AHEAD = 3;
+            const _Float16* const Ab = ((g & 1) ? sA1 : sA0) + r * kAPitch + hh * 8;
+            h8 af[4];
+#pragma unroll
+            for (int q = 0; q < AHEAD; ++q) af[q & 3] = *reinterpret_cast<const h8*>(Ab + (q % TMS) * 32 * kAPitch + (q / TMS) * 16);
+            __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
+#pragma unroll
+            for (int q = 0; q < NST; ++q) {
+                if (q + AHEAD < NST) af[(q + AHEAD) & 3] = *reinterpret_cast<const h8*>(Ab + ((q + AHEAD) % TMS) * 32 * kAPitch + ((q + AHEAD) / TMS) * 16);
+                acc[q % TMS] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, Bq.f[q / TMS]), af[q & 3], acc[q % TMS], 0, 0, 0);
+                if (q + AHEAD < NST) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+        };
+        // end of a step: bottleneck rows -> ring (pixels: value; rows outside the image: zero; pad columns untouched), then the 3x3 of the R rows
+        // whose three input rows are complete
+        auto finish_step = [&](int st) {
+            const int sbase = st * R;                      // staged-row index of the step's first row
+#pragma unroll
+            for (int i = 0; i < TMS; ++i) {
+                float v[16];
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const f32x4 bq = *reinterpret_cast<const f32x4*>(sBias + np * 32 + 8 * gq + 4 * hh);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float x = acc[i][4 * gq + q] + bq[q];
+                        v[4 * gq + q] = (L.flags & 2) ? fmaxf(x, 0.f) : x;
+                        acc[i][4 * gq + q] = 0.f;
+                    }
+                }
+                const int yimg = ys0 + sbase + pry[i];
+                const bool inimg = yimg >= 0 && yimg < H;
+                const int slot = (sbase + pry[i]) % NR;
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    const h4 qa = {_Float16(v[8 * gp + 0]), _Float16(v[8 * gp + 1]), _Float16(v[8 * gp + 2]), _Float16(v[8 * gp + 3])};
+                    const h4 qb = {_Float16(v[8 * gp + 4]), _Float16(v[8 * gp + 5]), _Float16(v[8 * gp + 6]), _Float16(v[8 * gp + 7])};
+                    const u32x2 xa = __builtin_bit_cast(u32x2, qa), xb = __builtin_bit_cast(u32x2, qb);
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(xa[0], xb[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(xa[1], xb[1], false, false);
+                    if (px[i] >= 0)
+                        *reinterpret_cast<u32x4*>(sT + (1 + slot * PW + px[i]) * kTPitch + np * 32 + 8 * (2 * gp + hh)) =
+                            inimg ? u32x4{s0[0], s1[0], s0[1], s1[1]} : u32x4{0u, 0u, 0u, 0u};
+                }
+            }
+            __syncthreads();                               // the step's bottleneck rows are in the ring
+            if (wave < TMS) {                              // 3x3: tile = wave; output row o = (first staged row of the step) - 1 + row of the position
+                const int o = ys0 + sbase - 1 + my_ry;
+                const int xo = my_x;
+                const bool valid = xo >= 0 && o >= ya && o < yb;
+                const int xs = xo >= 0 ? xo : 0;
+                // raster rows of the three taps' input rows o - 1, o, o + 1: ring slot ((row - ys0) mod NR); tap kx adds kx - 1 positions
+                const _Float16* tb[3];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    int sl = (o + ky - 1 - ys0) % NR;
+                    if (sl < 0) sl += NR;
+                    tb[ky] = sT + (sl * PW + xs) * kTPitch + hh * 8;          // = raster index (1 + sl * PW + xs) - 1: the kx = 0 tap
+                }
+                f32x16 acc3;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc3[e] = 0.f;
+                const _Float16* const Wb = sW3 + lane * 8;
+                h8 af[3], bf[3];
+                auto rd = [&](int tap, int kk, int slot) {
+                    af[slot] = *reinterpret_cast<const h8*>(tb[tap / 3] + (tap % 3) * kTPitch + kk * 16);
+                    bf[slot] = *reinterpret_cast<const h8*>(Wb + (tap * 8 + kk) * 512);
+                };
+                rd(0, 0, 0);
+                rd(0, 1, 1);
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) {
+                        const int st3 = tap * 8 + kk, nx = st3 + 2;
+                        if (nx < 72) rd(nx >> 3, nx & 7, nx % 3);
+                        acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[st3 % 3], af[st3 % 3], acc3, 0, 0, 0);
+                    }
+                }
+                float v[16];
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const f32x4 bq = *reinterpret_cast<const f32x4*>(sBias + 128 + 8 * gq + 4 * hh);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float x = acc3[4 * gq + q] + bq[q];
+                        v[4 * gq + q] = (L.flags & 4) ? fmaxf(x, 0.f) : x;
+                    }
+                }
+                const unsigned orow = valid ? unsigned((o * W + xs) * pitch) * 2u : kOOB;
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    const h4 qa = {_Float16(v[8 * gp + 0]), _Float16(v[8 * gp + 1]), _Float16(v[8 * gp + 2]), _Float16(v[8 * gp + 3])};
+                    const h4 qb = {_Float16(v[8 * gp + 4]), _Float16(v[8 * gp + 5]), _Float16(v[8 * gp + 6]), _Float16(v[8 * gp + 7])};
+                    const u32x2 xa = __builtin_bit_cast(u32x2, qa), xb = __builtin_bit_cast(u32x2, qb);
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(xa[0], xb[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(xa[1], xb[1], false, false);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rs_x, valid ? orow + unsigned(L.out_coff + 8 * (2 * gp + hh)) * 2u : kOOB, 0, 0);
+                }
+            }
+            __syncthreads();                               // 3x3 phase over: the ring slots of the oldest rows may be rewritten
+        };
+#pragma unroll
+        for (int i = 0; i < TMS; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+        issue_b(bs[0], 0);
+        issue_b(bs[1], 1);
+        issue_b(bs[2], 2);
+        __syncthreads();                                   // constants, 3x3 weights and the zeroed ring in place
+        __syncthreads();                                   // chunk 0 staged
+        auto step = [&](BSlot& Bq, int g) {
+            compute1(Bq, g);
+            issue_b(Bq, g + 3);
+            if (g % NC == NC - 1) finish_step(g / NC);     // its first barrier closes the compute phase, its second the 3x3 phase
+            else __syncthreads();
+        };
+        int g = 0;
+        for (; g + 3 <= G; g += 3) {
+            step(bs[0], g);
+            step(bs[1], g + 1);
+            step(bs[2], g + 2);
+        }
+        if (g < G) { step(bs[0], g); ++g; }
+        if (g < G) { step(bs[1], g); ++g; }
+    }
+}
+
 static size_t block_lds_bytes(int cfg, int H, int W, int R) {
     const int PW = W + 1;
+    if (cfg >= 3) {            // strip mode: 3x3 weights + ring of R + 2 raster rows (and two guard rows) + two chunk buffers + constants
+        const int tms = cfg == 3 ? 2 : 3;
+        return size_t(kW3Bytes) + size_t((R + 2) * PW + 2) * kTPitch * 2 + size_t(2) * 32 * tms * kAPitch * 2 + 160 * sizeof(float) + size_t(2) * kMaxK * 2;
+    }
     const int trows = cfg == 2 ? (R + 2) * PW + 2 : H * PW + 2 * PW + 2;
     const size_t stage = std::max(size_t(kW3Bytes), size_t(2) * 32 * (cfg == 0 ? 7 : (cfg == 1 ? 2 : 8)) * kAPitch * 2);
     return size_t(trows) * kTPitch * 2 + stage + 2 * 160 * sizeof(float) + size_t(4) * kMaxK * 2;
 }
 
-// 0 / 1: one workgroup per image (7 / 2 position tiles at most); 2: bands of `*rows` image rows with the halo recomputed (one layer per launch)
+// 0 / 1: one workgroup per image (7 / 2 position tiles at most, chains of layers); one layer on larger maps: 3 / 4 = strip mode (a workgroup slides
+// down a strip of rows, `*rows` rows = 2 / 3 tiles per step), else 2 = band mode (`*rows` image rows per workgroup, halo recomputed)
 static int block_cfg(int H, int W, int nlayers, int* rows) {
     const int PW = W + 1, ntiles = (H * PW + 31) / 32;
     *rows = 0;
     if (ntiles <= 2) return 1;
     if (ntiles <= 7) return 0;
     if (nlayers != 1) return -1;
+    if (PW <= 64) {
+        int R = 96 / PW;                       // R * PW raster positions per step in three tiles (two when one row takes more than 32)
+        if (R > H) R = H;
+        *rows = R;
+        return (R * PW + 31) / 32 <= 2 ? 3 : 4;
+    }
     int R = 256 / PW - 2;                      // (R + 2) * PW staged positions in 8 tiles
     if (R > H) R = H;
     if (R < 1) return -1;
     *rows = R;
     return 2;
+}
+
+static int strip_rows_for(int n, int H, int R) {          // image rows per strip: about one workgroup per CU, never fewer than 4 steps per strip
+    int nstrips = (256 + n - 1) / n;
+    const int most = H / (4 * R) > 0 ? H / (4 * R) : 1;
+    if (nstrips > most) nstrips = most;
+    if (nstrips < 1) nstrips = 1;
+    return (H + nstrips - 1) / nstrips;
 }
 
 bool DenseBlockEligible(const DenseBlockArgs& a) {
@@ -460,6 +775,7 @@ bool DenseBlockEligible(const DenseBlockArgs& a) {
     const int cfg = block_cfg(a.h, a.w, a.nlayers, &rows);
     if (cfg < 0 || block_lds_bytes(cfg, a.h, a.w, rows) > size_t(160) * 1024) return false;
     if (int64_t(a.n) * ((cfg == 2 ? (a.h + rows - 1) / rows : 1)) >= (int64_t(1) << 31)) return false;
+    if (cfg >= 3 && a.layer[0].K > kMaxK) return false;
     if ((a.pitch & 7) || (a.in_coff & 7) || (reinterpret_cast<uintptr_t>(a.x) & 15) || (reinterpret_cast<uintptr_t>(a.wfrag16) & 15) ||
         (reinterpret_cast<uintptr_t>(a.w16) & 15))
         return false;
@@ -487,7 +803,13 @@ hipError_t LaunchDenseBlockF16(const DenseBlockArgs& a_in, hipStream_t stream) {
     b.band_rows = rows;
     if (cfg == 0) dense_block_f16_kernel<0><<<dim3(b.n), dim3(512), lds, stream>>>(b);
     else if (cfg == 1) dense_block_f16_kernel<1><<<dim3(b.n), dim3(512), lds, stream>>>(b);
-    else dense_block_f16_kernel<2><<<dim3(b.n * ((b.h + rows - 1) / rows)), dim3(512), lds, stream>>>(b);
+    else if (cfg == 2) dense_block_f16_kernel<2><<<dim3(b.n * ((b.h + rows - 1) / rows)), dim3(512), lds, stream>>>(b);
+    else {
+        b.strip_rows = strip_rows_for(b.n, b.h, rows);
+        const int nstrips = (b.h + b.strip_rows - 1) / b.strip_rows;
+        if (cfg == 3) dense_strip_f16_kernel<2><<<dim3(b.n * nstrips), dim3(512), lds, stream>>>(b);
+        else dense_strip_f16_kernel<3><<<dim3(b.n * nstrips), dim3(512), lds, stream>>>(b);
+    }
     return hipGetLastError();
 }
 
@@ -516,6 +838,8 @@ hipError_t InitKernelsBlock() {
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_block_f16_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_block_f16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_block_f16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_strip_f16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_strip_f16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     return hipSuccess;
 }
 

@@ -1251,7 +1251,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
             // the per-band fixed cost -- 72 KB of 3x3 weights into LDS, raster reset, epilogue -- is paid 5 ... 28 times per image), so such steps are
             // only formed on request (IE_DENSE_BAND=1: tests, experiments).
             const int64_t ntiles = (s1.in.h * (s1.in.w + 1) + 31) / 32;
-            if (ntiles > 7 && (!env.flag("IE_DENSE_BAND") || 256 / (s1.in.w + 1) < 3)) return false;
+            if (ntiles > 7 && (!env.flag("IE_DENSE_BAND") || (s1.in.w + 1 > 64 && 256 / (s1.in.w + 1) < 3))) return false;
             // T must have no other reader: the fused kernel never writes it to memory
             for (size_t j = i + 2; j < plan.steps.size(); ++j) {
                 const Step& q = plan.steps[j];
