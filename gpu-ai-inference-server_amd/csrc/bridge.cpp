@@ -1111,8 +1111,8 @@ std::string describe_runtime(ModelObj& M, bool json, bool checksums = false) {
         o << ",\"weight_checksums\":[";
         for (size_t i = 0; i < M.lanes.size(); ++i) {
             std::vector<char> host(M.lanes[i]->weight_bytes());
-            (void)hipSetDevice(M.lanes[i]->device());
-            if (hipMemcpy(host.data(), M.lanes[i]->weights(), host.size(), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); host.clear(); }
+            try { M.lanes[i]->CopySync(host.data(), M.lanes[i]->weights(), host.size(), hipMemcpyDeviceToHost, "hipMemcpy(weight checksum)"); }
+            catch (const std::exception&) { (void)hipGetLastError(); host.clear(); }
             o << (i ? "," : "") << "\"" << std::hex << fnv1a64(host.data(), host.size()) << std::dec << "\"";
         }
         // and of everything derived from it per lane (half / fragment-major / Winograd U / bf16x6 / e4m3 + scales)

@@ -222,6 +222,18 @@ void DeviceModel::FreeInstance(PlanInstance& pi) {
     pi.u8_stage.clear();
 }
 
+void DeviceModel::CopySync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, const char* what) {
+    if (bytes == 0) return;
+    check(hipMemcpyAsync(dst, src, bytes, kind, stream_), what);
+    check(hipStreamSynchronize(stream_), what);
+}
+
+void DeviceModel::ZeroSync(void* dst, size_t bytes, const char* what) {
+    if (bytes == 0) return;
+    check(hipMemsetAsync(dst, 0, bytes, stream_), what);
+    check(hipStreamSynchronize(stream_), what);
+}
+
 // Plan + allocate one instance (and, the first time on this device, put the packed weights into HBM).
 void DeviceModel::BuildInstance(PlanInstance& pi, const std::vector<std::vector<int64_t>>& shapes) {
     pi.plan = BuildPlan(*model_, shapes, precision_);
@@ -232,10 +244,10 @@ void DeviceModel::BuildInstance(PlanInstance& pi, const std::vector<std::vector<
             check(hipMalloc(reinterpret_cast<void**>(&w_->d_weights), std::max<size_t>(w_->weight_floats, 4) * sizeof(float)), "hipMalloc(weights)");
             w_->device_bytes += w_->weight_floats * sizeof(float);
             if (upload_weights_) {
-                check(hipMemcpy(w_->d_weights, pi.plan.weights.data(), w_->weight_floats * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy(weights)");
+                CopySync(w_->d_weights, pi.plan.weights.data(), w_->weight_floats * sizeof(float), hipMemcpyHostToDevice, "hipMemcpy(weights)");
                 w_->uploaded = true;
             } else {
-                check(hipMemset(w_->d_weights, 0, w_->weight_floats * sizeof(float)), "hipMemset(weights)");
+                ZeroSync(w_->d_weights, w_->weight_floats * sizeof(float), "hipMemset(weights)");
             }
             if (precision_ == Precision::F16 || precision_ == Precision::F8) {
                 check(hipMalloc(&w_->d_weights16, std::max<size_t>(w_->weight_floats, 8) * 2), "hipMalloc(weights16)");
@@ -260,7 +272,7 @@ void DeviceModel::BuildInstance(PlanInstance& pi, const std::vector<std::vector<
                 }
                 if (precision_ == Precision::F8) {
                     check(hipMalloc(&w_->d_weights8, std::max<size_t>(w_->weight_floats, 16)), "hipMalloc(weights8)");
-                    check(hipMemset(w_->d_weights8, 0, std::max<size_t>(w_->weight_floats, 16)), "hipMemset(weights8)");
+                    ZeroSync(w_->d_weights8, std::max<size_t>(w_->weight_floats, 16), "hipMemset(weights8)");
                     w_->device_bytes += w_->weight_floats;
                     int64_t aux = 0;
                     auto add8 = [&](const Step& st, int i) {
@@ -479,7 +491,7 @@ std::vector<std::pair<std::string, uint64_t>> DeviceModel::MirrorChecksums() {
     auto fnv = [](uint64_t h, const char* p, size_t n) { for (size_t i = 0; i < n; ++i) { h ^= uint8_t(p[i]); h *= 0x100000001B3ull; } return h; };
     auto pull = [&](const void* dev, size_t bytes) {
         host.resize(bytes);
-        if (bytes) check(hipMemcpy(host.data(), dev, bytes, hipMemcpyDeviceToHost), "hipMemcpy(mirror)");
+        if (bytes) CopySync(host.data(), dev, bytes, hipMemcpyDeviceToHost, "hipMemcpy(mirror)");
     };
     constexpr uint64_t kBasis = 0xCBF29CE484222325ull;
     if (W.d_weights16) { pull(W.d_weights16, W.weight_floats * 2); out.push_back({"half", fnv(kBasis, host.data(), host.size())}); }

@@ -151,6 +151,11 @@ public:
     // FNV-1a of every mirror derived from the fp32 blob as it sits in HBM (half / fragment-major / Winograd U / bf16x6 / e4m3 + scales):
     // a replica filled by the weight broadcast must end up with the primary's derived data too.  Call with the lane held.
     std::vector<std::pair<std::string, uint64_t>> MirrorChecksums();
+    // Synchronous copies / fills on THIS model's (non-blocking) stream.  The legacy-stream forms (hipMemcpy, hipMemset) are refused by the runtime
+    // while any other thread captures a graph ("would make the legacy stream depend on a capturing stream"): replicas of one model load, tune and
+    // capture concurrently, so nothing in the engine may touch the legacy stream.
+    void CopySync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, const char* what);
+    void ZeroSync(void* dst, size_t bytes, const char* what);
     size_t weight_bytes() const { return w_->weight_floats * sizeof(float); }
     size_t device_bytes() const { return device_bytes_ + w_->device_bytes.load(); }
     PlanInstance* current() { return current_; }

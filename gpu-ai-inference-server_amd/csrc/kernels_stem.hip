@@ -13,6 +13,10 @@
 
 #include "kernels.h"
 
+#ifndef STEM_ABLATE
+#define STEM_ABLATE 0     // scripts/probes/stem_probe.cpp builds variants with parts of the kernel switched off
+#endif
+
 namespace ie {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -54,14 +58,29 @@ __global__ __launch_bounds__(64 * WAVES) void conv_stem_kernel(const ConvArgs a,
     const int H = a.in.h, W = a.in.w, OH = a.out.h, OW = a.out.w, Cout = a.out.c;
     const int opitch = int(a.out.sw);
 
-    // ---- preamble: weights [Cout][KH][KW][CIN] (fp32) -> sWt[n][(c*KH + ky)*8 + kx], zero padded ----
-    for (int q = tid; q < 64 * KP; q += NT) {
-        const int n = q / KP, k = q - n * KP;
-        const int gi = k >> 3, kx = k & 7;
-        const int c = gi / KH, ky = gi - c * KH;
-        float v = 0.f;
-        if (n < Cout && gi < G && kx < KW) v = a.w[((n * KH + ky) * KW + kx) * CIN + c];
-        sWt[n * BP + k] = T(v);
+    // ---- preamble: weights [Cout][KH][KW][CIN] (fp32) -> sWt[n][(c*KH + ky)*8 + kx], zero padded; eight independent loads in flight per
+    //      thread (one dependent load per trip cost every workgroup ~40 L2 round trips before its first tile) ----
+    {
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, Cout * KH * KW * CIN * 4, 0x00020000);
+        constexpr int WTRIPS = ((64 * KP + NT - 1) / NT + 7) / 8 * 8;
+        for (int t0 = 0; t0 < WTRIPS; t0 += 8) {
+            float wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = tid + (t0 + u) * NT;
+                const int n = q / KP, k = q - n * KP;
+                const int gi = k >> 3, kx = k & 7;
+                const int c = gi / KH, ky = gi - c * KH;
+                const bool ok = q < 64 * KP && n < Cout && gi < G && kx < KW;
+                wv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_w, ok ? unsigned(((n * KH + ky) * KW + kx) * CIN + c) * 4u : 0x80000000u, 0, 0));
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = tid + (t0 + u) * NT;
+                const int n = q / KP, k = q - n * KP;
+                if (q < 64 * KP) sWt[n * BP + k] = T(wv[u]);
+            }
+        }
     }
     for (int q = tid; q < 64; q += NT) sBias[q] = (a.bias != nullptr && q < Cout) ? a.bias[q] : 0.f;
 
@@ -70,32 +89,43 @@ __global__ __launch_bounds__(64 * WAVES) void conv_stem_kernel(const ConvArgs a,
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
         a.out.p, 0, int((int64_t(a.out.n) * OH * OW - 1) * opitch * esz + Cout * esz), 0x00020000);
 
+    // The window gather: element e = tid + i * NT of the window is (c, wy, wx) whatever the tile, so its offset relative to the window's
+    // corner and its LDS slot are computed ONCE; per tile a load costs two compares and an add.  (Recomputing them per tile let the
+    // register allocator place 64-bit address temporaries over registers of loads still in flight: an s_waitcnt vmcnt in the middle of
+    // the gather, behind the previous tile's stores -- every tile paid a store round trip plus a load round trip.)
+    int rel[PIT];
+    unsigned slot[PIT];              // wx | wy << 8 | LDS element offset << 16; wy = 255 for the padding elements e >= ELEMS (never in bounds)
+#pragma unroll
+    for (int i = 0; i < PIT; ++i) {
+        const int e = tid + i * NT;
+        const int c = e / (WROWS * WCOLS), rem2 = e - c * (WROWS * WCOLS);
+        const int wy = rem2 / WCOLS, wx = rem2 - wy * WCOLS;
+        rel[i] = (c * H + wy) * W + wx;
+        slot[i] = e < ELEMS ? unsigned(wx | (wy << 8) | (((c * WROWS + wy) * WP + wx) << 16)) : 0xFF00u;
+    }
+    static_assert(CIN * WROWS * WP < 65536 && WROWS < 255 && WCOLS < 256, "slot packing");
     float pv[PIT];
     auto issue = [&](int tile) {
         const int b = tile / (g.tiles_x * g.tiles_y);
         const int rem = tile - b * (g.tiles_x * g.tiles_y);
         const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
         const int iy0 = ty * TH * S - a.pt, ix0 = tx * TW * S - a.pl;
+        const int base = (b * CIN * H + iy0) * W + ix0;
+        unsigned off[PIT];
 #pragma unroll
         for (int i = 0; i < PIT; ++i) {
-            const int e = tid + i * NT;
-            const int c = e / (WROWS * WCOLS), rem2 = e - c * (WROWS * WCOLS);
-            const int wy = rem2 / WCOLS, wx = rem2 - wy * WCOLS;
-            const int iy = iy0 + wy, ix = ix0 + wx;
-            const bool ok = e < ELEMS && unsigned(iy) < unsigned(H) && unsigned(ix) < unsigned(W);
-            const unsigned off = ok ? unsigned(((b * CIN + c) * H + iy) * W + ix) * 4u : OOB;
-            pv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, off, 0, 0));
+            const int iy = iy0 + int((slot[i] >> 8) & 0xFFu), ix = ix0 + int(slot[i] & 0xFFu);
+            const bool ok = unsigned(iy) < unsigned(H) && unsigned(ix) < unsigned(W);
+            off[i] = (ok && STEM_ABLATE != 2) ? unsigned(base + rel[i]) * 4u : OOB;
         }
+#pragma unroll
+        for (int i = 0; i < PIT; ++i) pv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, off[i], 0, 0));
     };
     auto commit = [&](int buf) {
         T* const win = sWin + buf * WIN;
 #pragma unroll
-        for (int i = 0; i < PIT; ++i) {
-            const int e = tid + i * NT;
-            const int c = e / (WROWS * WCOLS), rem2 = e - c * (WROWS * WCOLS);
-            const int wy = rem2 / WCOLS, wx = rem2 - wy * WCOLS;
-            if (e < ELEMS) win[(c * WROWS + wy) * WP + wx] = T(pv[i]);
-        }
+        for (int i = 0; i < PIT; ++i)
+            if ((slot[i] & 0xFF00u) != 0xFF00u) win[slot[i] >> 16] = T(pv[i]);
     };
 
     f32x16 acc[2];
@@ -149,7 +179,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_stem_kernel(const ConvArgs a,
         const int rem = tile - b * (g.tiles_x * g.tiles_y);
         const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
         const int oy = ty * TH + oyl, ox = tx * TW + oxl;
-        const unsigned rowoff = (oy < OH && ox < OW) ? unsigned(((b * OH + oy) * OW + ox) * opitch * esz) : OOB;
+        const unsigned rowoff = (oy < OH && ox < OW && STEM_ABLATE != 1) ? unsigned(((b * OH + oy) * OW + ox) * opitch * esz) : OOB;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             float v[16];
@@ -212,9 +242,9 @@ __global__ __launch_bounds__(64 * WAVES) void conv_stem_kernel(const ConvArgs a,
         const int ntile = tile + gridDim.x;
         if (ntile < g.num_tiles) issue(ntile);
         __builtin_amdgcn_sched_barrier(0);
-        compute(buf);
+        if (STEM_ABLATE != 3) compute(buf);
         __builtin_amdgcn_sched_barrier(0);
-        epilogue(tile);
+        if (STEM_ABLATE != 4) epilogue(tile);
         if (ntile < g.num_tiles) commit(buf ^ 1);      // the other buffer: its last readers passed the previous barrier
         __syncthreads();
         tile = ntile;
