@@ -21,7 +21,7 @@ const char* const kNames[] = {
     "IE_VERSION_ORDER",        // go: numeric "latest version" like the Go server (default: the C++ repository's lexicographic order)
     "IE_ROCTX",                // 1: one ROCTX range per ModelInfer
     // ---- planner -----------------------------------------------------------------------------------------------------------------
-    "IE_NO_POOL_SWAP", "IE_NO_DENSE_FUSE", "IE_NO_DENSE_BLOCK", "IE_DENSE_BAND", "IE_NO_DUAL_F8", "IE_FUSE_MAX_M", "IE_FUSE_PB",
+    "IE_NO_POOL_SWAP", "IE_NO_DENSE_FUSE", "IE_NO_DENSE_BLOCK", "IE_DENSE_BAND", "IE_NO_DUAL_F8", "IE_NO_STEM_POOL", "IE_FUSE_MAX_M", "IE_FUSE_PB",
     "IE_FORCE_ALGO", "IE_FORCE_TILE", "IE_FORCE_SPLITK",      // tests: pin the kernel family / tile / split-K of every conv
     // ---- executor ----------------------------------------------------------------------------------------------------------------
     "IE_AUTOTUNE", "IE_TUNE_CACHE", "IE_TUNE_BATCHES", "IE_TUNE_ON_DEMAND", "IE_TUNE_HOT", "IE_TUNE_LOG",

@@ -828,6 +828,44 @@ void DeviceModel::Autotune(PlanInstance& pi, size_t nsteps, bool allow_search) {
                 w_->tune_dirty = true;
                 continue;
             }
+            if (s.algo == ConvAlgo::StemPool) {
+                // fused vs the two launches: one timed choice (tile 1 / 0), cached like the others
+                std::vector<int64_t> keys = {s.in.n, s.in.h, s.in.w, s.out.c, s.out.pitch, s.out.f8 ? 2 : 1, int64_t(ConvAlgo::StemPool)};
+                int choice = -1;
+                {
+                    std::lock_guard<std::mutex> g(w_->tune_mu);
+                    auto hit = w_->tune_cache.find(keys);
+                    if (hit != w_->tune_cache.end()) choice = hit->second.first;
+                }
+                const bool can = ConvStemPoolEligible(MakeConvArgs(pi, s));
+                if (choice < 0 && allow_search && can && !(s.out.f8 && !w_->f8_ready)) {
+                    searched = true;
+                    float best[2] = {1e30f, 1e30f};
+                    for (int t = 0; t < 2; ++t) {
+                        Step trial = s;
+                        trial.tile = t;
+                        LaunchStep(pi, trial, stream_);
+                        for (int rep = 0; rep < 3; ++rep) {
+                            if (scrub) check(hipMemsetAsync(scrub, 0, kScrubBytes, stream_), "hipMemsetAsync(scrub)");
+                            check(hipEventRecord(e0, stream_), "hipEventRecord");
+                            LaunchStep(pi, trial, stream_);
+                            check(hipEventRecord(e1, stream_), "hipEventRecord");
+                            check(hipEventSynchronize(e1), "hipEventSynchronize");
+                            float ms = 0;
+                            check(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime");
+                            best[t] = std::min(best[t], ms);
+                        }
+                    }
+                    choice = best[1] <= best[0] ? 1 : 0;
+                    if (env_.get("IE_TUNE_LOG")) std::fprintf(stderr, "[tune] stem + pool %s: one launch %.1f us, two launches %.1f us\n", s.name.c_str(), best[1] * 1e3, best[0] * 1e3);
+                    std::lock_guard<std::mutex> g(w_->tune_mu);
+                    w_->tune_cache[keys] = {choice, 1};
+                    w_->tune_dirty = true;
+                }
+                if (!can) choice = 0;
+                if (choice >= 0) s.tile = choice;
+                continue;
+            }
             if (s.algo == ConvAlgo::DenseBlock) {
                 // the parts get their own kernel choices (what runs when the chain kernel declines, and the yardstick); chain vs parts is
                 // one more timed choice (tile 1 = one launch, 0 = the 2n plain launches)
@@ -1359,6 +1397,13 @@ void DeviceModel::LaunchStep(const PlanInstance& pi, const Step& s_in, hipStream
                 }
                 break;
             }
+            if (s.algo == ConvAlgo::StemPool) {
+                // the stem conv and the max pool behind it in one launch (out = the pooled tensor); the two plain steps when the launcher declines
+                const ConvArgs a = MakeConvArgs(pi, s);
+                if (s.tile != 0 && ConvStemPoolEligible(a)) check(LaunchConvStemPool(a, stream_), "conv_stem_pool");
+                else for (const Step& q : s.parts) LaunchStep(pi, q, stream_);
+                break;
+            }
             if (s.algo == ConvAlgo::DenseBlock) {
                 DenseBlockArgs b;
                 if (s.tile != 0 && MakeBlockArgs(pi, s, &b) && DenseBlockEligible(b)) check(LaunchDenseBlockF16(b, stream_), "dense_block_f16");
@@ -1508,6 +1553,7 @@ static std::string kernel_label(const Step& s) {
                                              : s.in.f16 ? "conv_direct_kernel<f16,t" : "conv_direct_kernel<f32,t";
                 return std::string(k) + std::to_string(s.tile) + ">";
             }
+            if (s.algo == ConvAlgo::StemPool) return s.tile != 0 ? (s.out.f8 ? "conv_stem_kernel<f16,pool,e4m3 out>" : "conv_stem_kernel<f16,pool>") : "stem + pool (2 launches)";
             if (s.algo == ConvAlgo::Stem) return s.out.f8 ? "conv_stem_kernel<f16,e4m3 out>" : (s.out.f16 ? "conv_stem_kernel<f16>" : "conv_stem_kernel<f32>");
             if (s.algo == ConvAlgo::Ws1x1) return std::string(s.in.f16 ? "conv1x1_ws_f16_kernel<t" : "conv1x1_ws_f32_kernel<t") + std::to_string(s.tile) + ">";
             if (s.algo == ConvAlgo::Ws3x3) return "conv3x3_ws_f16_kernel<t" + std::to_string(s.tile) + ">";

@@ -128,6 +128,9 @@ hipError_t InitKernelsDirect();
 // half arithmetic + half output in fp16 mode, fp32 otherwise.
 bool ConvStemEligible(const ConvArgs& a);
 hipError_t LaunchConvStem(const ConvArgs& a, hipStream_t stream);
+// The stem AND the 3x3 / stride 2 / pad 1 max pool behind it in one launch (fp16 / fp8 modes): `a` is the stem's argument set with out = the POOLED tensor.
+bool ConvStemPoolEligible(const ConvArgs& a);
+hipError_t LaunchConvStemPool(const ConvArgs& a, hipStream_t stream);
 hipError_t InitKernelsStem();
 // Winograd F(2x2, 3x3) conv (kernels_wino.hip): fp32, 3x3 / stride 1 / pad 1, 32 output channels, even H and W; a.wfrag = the transformed
 // weights U (16 x Cout x Cin floats, fragment-major) built by LaunchWinogradWeights.  tile: 0..3 = output tiles per workgroup.

@@ -9,6 +9,12 @@
 //   fp16 mode: window and weights as halfs, v_mfma_f32_32x32x16_f16, half NHWC output.
 //   fp32 mode: float window and weights, v_mfma_f32_32x32x2_f32 (4 MFMAs per 16-byte weight fragment), float NHWC output.
 // D = W x A^T: a lane owns one output pixel and quads of channels (16-byte stores).
+//
+// POOL variant (fp16 / fp8 modes): the 3x3 / stride 2 / pad 1 max pool that follows the stem in DenseNet and ResNet runs in the same launch.  A
+// workgroup of 8 waves owns 7 x 7 POOLED pixels = a 15 x 15 patch of conv outputs inside its 16 x 16 tile (origin 2 * 7 * t - 1: one halo row / column
+// recomputed per side, 1.31x the conv work, which is cheap in half precision); the ReLU'd conv tile goes to LDS as halfs (zeros outside the image:
+// after a ReLU they never win a max), a barrier, and 49 x Cout/8 threads each take the max of nine 16-byte reads and store 8 channels.  The
+// 112 x 112 x 64 tensor between the two ops -- the largest of the whole network -- is never written or read.
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
@@ -25,14 +31,19 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
 struct StemGeom {
     int tiles_x, tiles_y, num_tiles;
+    int oh, ow;                       // conv output size (== the output tensor's unless the max pool is fused)
 };
 
+constexpr int kStemPoolPitch = 72;    // halfs per conv pixel in the POOL variant's LDS tile: 144 B, 16-byte aligned, 4 banks apart
+
 // T = _Float16 (fp16 mode) or float (fp32 mode)
-template <typename T, int CIN, int KH, int KW, int S, int WAVES>
+template <typename T, int CIN, int KH, int KW, int S, int WAVES, bool POOL, bool VEC>
 __global__ __launch_bounds__(64 * WAVES) void conv_stem_kernel(const ConvArgs a, const StemGeom g) {
+    static_assert(!POOL || (sizeof(T) == 2 && WAVES == 8 && S == 2), "the fused max pool: half arithmetic, 16 x 16 conv tiles");
     constexpr bool HALF = sizeof(T) == 2;
     constexpr int NT = 64 * WAVES, TW = 16, TH = 2 * WAVES;
     constexpr int G = CIN * KH;                          // (c, ky) groups of 8 k each
@@ -45,17 +56,28 @@ __global__ __launch_bounds__(64 * WAVES) void conv_stem_kernel(const ConvArgs a,
     static_assert(WP >= WCOLS, "window pitch too small");
     constexpr int BP = KP + (HALF ? 8 : 4);              // weight row pitch (16-byte units odd)
     constexpr int WIN = CIN * WROWS * WP;
-    constexpr int ELEMS = CIN * WROWS * WCOLS, PIT = (ELEMS + NT - 1) / NT;
+    // VEC (image width % 4 == 0): the window is gathered as 16-byte groups of four columns.  The first column the tile needs, ix0 = S * cx0 - 3, is
+    // 1 (3 with POOL) past a multiple of four, so XSH more columns are loaded on the left; in LDS the columns are shifted by PSH so that the 8-column
+    // MFMA operands of the half variant still start on a 4-byte boundary.  3 loads per thread and tile instead of 10.
+    static_assert(S == 2 && KW == 7, "column alignment of the vector gather");
+    constexpr int XSH = POOL ? 3 : 1;
+    constexpr int GR = (XSH + WCOLS + 3) / 4;             // 16-byte groups per window row
+    constexpr int PSH = VEC ? (HALF ? 4 - XSH : 0) : 0;   // LDS column of the first loaded column
+    constexpr int CB = VEC ? XSH + PSH : 0;               // LDS column of the first column the tile needs
+    static_assert(!VEC || PSH + 4 * GR <= WP, "window pitch too small for the vector gather");
+    constexpr int ELEMS = VEC ? CIN * WROWS * GR : CIN * WROWS * WCOLS, PIT = (ELEMS + NT - 1) / NT;
     constexpr unsigned OOB = 0x80000000u;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_stem[];
     T* const sWt = reinterpret_cast<T*>(smem_stem);      // [64][BP]
     T* const sWin = sWt + 64 * BP;                       // [2][CIN][WROWS][WP]
     float* const sBias = reinterpret_cast<float*>(sWin + 2 * WIN);   // [64]
+    _Float16* const sC = reinterpret_cast<_Float16*>(sBias + 64);    // POOL: [TH * TW][kStemPoolPitch] conv tile
+    constexpr int PT = (TH - 2) / 2;                                 // POOL: pooled rows / columns per tile
 
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int H = a.in.h, W = a.in.w, OH = a.out.h, OW = a.out.w, Cout = a.out.c;
+    const int H = a.in.h, W = a.in.w, OH = g.oh, OW = g.ow, Cout = a.out.c;
     const int opitch = int(a.out.sw);
 
     // ---- preamble: weights [Cout][KH][KW][CIN] (fp32) -> sWt[n][(c*KH + ky)*8 + kx], zero padded; eight independent loads in flight per
@@ -87,45 +109,59 @@ __global__ __launch_bounds__(64 * WAVES) void conv_stem_kernel(const ConvArgs a,
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(a.in.p, 0, int(a.in_bytes), 0x00020000);
     const int esz = a.out.f8 ? 1 : (a.out.f16 ? 2 : 4);
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
-        a.out.p, 0, int((int64_t(a.out.n) * OH * OW - 1) * opitch * esz + Cout * esz), 0x00020000);
+        a.out.p, 0, int((int64_t(a.out.n) * a.out.h * a.out.w - 1) * opitch * esz + Cout * esz), 0x00020000);
 
     // The window gather: element e = tid + i * NT of the window is (c, wy, wx) whatever the tile, so its offset relative to the window's
     // corner and its LDS slot are computed ONCE; per tile a load costs two compares and an add.  (Recomputing them per tile let the
     // register allocator place 64-bit address temporaries over registers of loads still in flight: an s_waitcnt vmcnt in the middle of
     // the gather, behind the previous tile's stores -- every tile paid a store round trip plus a load round trip.)
     int rel[PIT];
-    unsigned slot[PIT];              // wx | wy << 8 | LDS element offset << 16; wy = 255 for the padding elements e >= ELEMS (never in bounds)
+    unsigned slot[PIT];              // column | wy << 8 | LDS element offset << 16; wy = 255 for the padding elements e >= ELEMS (never in bounds)
+    constexpr int EPR = VEC ? GR : WCOLS, EW = VEC ? 4 : 1;          // elements per window row, columns per element
 #pragma unroll
     for (int i = 0; i < PIT; ++i) {
         const int e = tid + i * NT;
-        const int c = e / (WROWS * WCOLS), rem2 = e - c * (WROWS * WCOLS);
-        const int wy = rem2 / WCOLS, wx = rem2 - wy * WCOLS;
+        const int c = e / (WROWS * EPR), rem2 = e - c * (WROWS * EPR);
+        const int wy = rem2 / EPR, wx = (rem2 - wy * EPR) * EW;
         rel[i] = (c * H + wy) * W + wx;
-        slot[i] = e < ELEMS ? unsigned(wx | (wy << 8) | (((c * WROWS + wy) * WP + wx) << 16)) : 0xFF00u;
+        slot[i] = e < ELEMS ? unsigned(wx | (wy << 8) | (((c * WROWS + wy) * WP + wx + PSH) << 16)) : 0xFF00u;
     }
-    static_assert(CIN * WROWS * WP < 65536 && WROWS < 255 && WCOLS < 256, "slot packing");
-    float pv[PIT];
+    static_assert(CIN * WROWS * WP < 65536 && WROWS < 255 && WCOLS + 8 < 256, "slot packing");
+    float pv[VEC ? 1 : PIT];
+    f32x4 pv4[VEC ? PIT : 1];
     auto issue = [&](int tile) {
         const int b = tile / (g.tiles_x * g.tiles_y);
         const int rem = tile - b * (g.tiles_x * g.tiles_y);
         const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
-        const int iy0 = ty * TH * S - a.pt, ix0 = tx * TW * S - a.pl;
+        const int cy0 = POOL ? ty * 2 * PT - 1 : ty * TH, cx0 = POOL ? tx * 2 * PT - 1 : tx * TW;     // first conv output of the tile
+        const int iy0 = cy0 * S - a.pt, ix0 = cx0 * S - a.pl - (VEC ? XSH : 0);                      // VEC: ix0 % 4 == 0
         const int base = (b * CIN * H + iy0) * W + ix0;
         unsigned off[PIT];
 #pragma unroll
         for (int i = 0; i < PIT; ++i) {
             const int iy = iy0 + int((slot[i] >> 8) & 0xFFu), ix = ix0 + int(slot[i] & 0xFFu);
-            const bool ok = unsigned(iy) < unsigned(H) && unsigned(ix) < unsigned(W);
+            const bool ok = unsigned(iy) < unsigned(H) && unsigned(ix) < unsigned(W);          // VEC: W % 4 == 0, a group is inside or outside as a whole
             off[i] = (ok && STEM_ABLATE != 2) ? unsigned(base + rel[i]) * 4u : OOB;
         }
 #pragma unroll
-        for (int i = 0; i < PIT; ++i) pv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, off[i], 0, 0));
+        for (int i = 0; i < PIT; ++i) {
+            if constexpr (VEC) pv4[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off[i], 0, 0));
+            else pv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, off[i], 0, 0));
+        }
     };
     auto commit = [&](int buf) {
         T* const win = sWin + buf * WIN;
 #pragma unroll
-        for (int i = 0; i < PIT; ++i)
-            if ((slot[i] & 0xFF00u) != 0xFF00u) win[slot[i] >> 16] = T(pv[i]);
+        for (int i = 0; i < PIT; ++i) {
+            if ((slot[i] & 0xFF00u) == 0xFF00u) continue;
+            T* const d = win + (slot[i] >> 16);
+            if constexpr (!VEC) d[0] = T(pv[i]);
+            else if constexpr (HALF) {         // PSH is odd: columns 1-2 of the group share an aligned dword
+                d[0] = T(pv4[i][0]);
+                *reinterpret_cast<h2*>(d + 1) = h2{_Float16(pv4[i][1]), _Float16(pv4[i][2])};
+                d[3] = T(pv4[i][3]);
+            } else *reinterpret_cast<f32x4*>(d) = pv4[i];
+        }
     };
 
     f32x16 acc[2];
@@ -135,7 +171,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_stem_kernel(const ConvArgs a,
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 
     const int oyl = 2 * wave + (r >> 4), oxl = r & 15;     // this lane's output pixel inside the tile
-    const int lane_base = S * oyl * WP + S * oxl;
+    const int lane_base = S * oyl * WP + S * oxl + CB;
     auto compute = [&](int buf) {
         const T* const win = sWin + buf * WIN + lane_base;
         if constexpr (HALF) {
@@ -232,6 +268,69 @@ __global__ __launch_bounds__(64 * WAVES) void conv_stem_kernel(const ConvArgs a,
         }
     };
 
+    // POOL: ReLU'd conv tile -> LDS (halfs, zeros outside the image) ...
+    auto epilogue_to_lds = [&](int tile) {
+        const int rem = tile % (g.tiles_x * g.tiles_y);
+        const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
+        const int cy = ty * 2 * PT - 1 + oyl, cx = tx * 2 * PT - 1 + oxl;
+        const bool valid = unsigned(cy) < unsigned(OH) && unsigned(cx) < unsigned(OW);
+        _Float16* const dst = sC + (oyl * TW + oxl) * kStemPoolPitch;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float v[16];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(sBias + j * 32 + 8 * gq + 4 * hh);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[4 * gq + q] = valid ? fmaxf(acc[j][4 * gq + q] + bq[q], 0.f) : 0.f;
+                    acc[j][4 * gq + q] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                const h4 qa = {_Float16(v[8 * gp + 0]), _Float16(v[8 * gp + 1]), _Float16(v[8 * gp + 2]), _Float16(v[8 * gp + 3])};
+                const h4 qb = {_Float16(v[8 * gp + 4]), _Float16(v[8 * gp + 5]), _Float16(v[8 * gp + 6]), _Float16(v[8 * gp + 7])};
+                const u32x2 xa = __builtin_bit_cast(u32x2, qa), xb = __builtin_bit_cast(u32x2, qb);
+                const auto s0 = __builtin_amdgcn_permlane32_swap(xa[0], xb[0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(xa[1], xb[1], false, false);
+                *reinterpret_cast<u32x4*>(dst + j * 32 + 8 * (2 * gp + hh)) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+            }
+        }
+    };
+    // ... and, after a barrier, one thread per (pooled pixel, 8 channels): max of the 3 x 3 window, one store
+    auto pool_store = [&](int tile) {
+        const int cgs = Cout >> 3;
+        if (tid >= PT * PT * cgs) return;
+        const int b = tile / (g.tiles_x * g.tiles_y);
+        const int rem = tile - b * (g.tiles_x * g.tiles_y);
+        const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
+        const int pp = tid / cgs, cg = tid - pp * cgs;
+        const int ply = pp / PT, plx = pp - ply * PT;
+        const int py = ty * PT + ply, px = tx * PT + plx;
+        const _Float16* const src = sC + ((2 * ply) * TW + 2 * plx) * kStemPoolPitch + cg * 8;
+        h8 m = *reinterpret_cast<const h8*>(src);
+#pragma unroll
+        for (int d = 1; d < 9; ++d) m = __builtin_elementwise_max(m, *reinterpret_cast<const h8*>(src + ((d / 3) * TW + (d % 3)) * kStemPoolPitch));
+        const bool ok = py < a.out.h && px < a.out.w;
+        const unsigned off = ok ? unsigned((((b * a.out.h + py) * a.out.w + px) * opitch + cg * 8) * esz) : OOB;
+        if (a.out.f8) {
+            unsigned d[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float q4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) q4[e] = __builtin_fminf(float(m[4 * q + e]) * a.out_qscale, 448.f);
+                int pk = __builtin_amdgcn_cvt_pk_fp8_f32(q4[0], q4[1], 0, false);
+                pk = __builtin_amdgcn_cvt_pk_fp8_f32(q4[2], q4[3], pk, true);
+                d[q] = unsigned(pk);
+            }
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{d[0], d[1]}, rs_out, off, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, m), rs_out, off, 0, 0);
+        }
+    };
+
     int tile = blockIdx.x, buf = 0;
     if (tile < g.num_tiles) {
         issue(tile);
@@ -244,7 +343,13 @@ __global__ __launch_bounds__(64 * WAVES) void conv_stem_kernel(const ConvArgs a,
         __builtin_amdgcn_sched_barrier(0);
         if (STEM_ABLATE != 3) compute(buf);
         __builtin_amdgcn_sched_barrier(0);
-        if (STEM_ABLATE != 4) epilogue(tile);
+        if constexpr (POOL) {
+            epilogue_to_lds(tile);
+            __syncthreads();
+            pool_store(tile);
+        } else {
+            if (STEM_ABLATE != 4) epilogue(tile);
+        }
         if (ntile < g.num_tiles) commit(buf ^ 1);      // the other buffer: its last readers passed the previous barrier
         __syncthreads();
         tile = ntile;
@@ -252,7 +357,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_stem_kernel(const ConvArgs a,
     }
 }
 
-template <typename T, int CIN, int KH, int KW, int S, int WAVES>
+template <typename T, int CIN, int KH, int KW, int S, int WAVES, bool POOL = false>
 static size_t stem_lds_bytes() {
     constexpr bool HALF = sizeof(T) == 2;
     constexpr int TH = 2 * WAVES, G = CIN * KH;
@@ -260,7 +365,7 @@ static size_t stem_lds_bytes() {
     constexpr int WROWS = S * (TH - 1) + KH;
     constexpr int WP = HALF ? (S == 2 ? 48 : 96) : 40;
     constexpr int BP = KP + (HALF ? 8 : 4);
-    return size_t(64 * BP + 2 * CIN * WROWS * WP) * sizeof(T) + 64 * sizeof(float);
+    return size_t(64 * BP + 2 * CIN * WROWS * WP) * sizeof(T) + 64 * sizeof(float) + (POOL ? size_t(TH * 16 * kStemPoolPitch) * 2 : 0);
 }
 
 bool ConvStemEligible(const ConvArgs& a) {
@@ -276,6 +381,20 @@ bool ConvStemEligible(const ConvArgs& a) {
     return in_elems * 4 < (int64_t(1) << 31) && out_elems * 4 < (int64_t(1) << 31);
 }
 
+// 16-byte gathers: every image row starts on a 16-byte boundary
+static bool stem_vec_ok(const ConvArgs& a) { return (a.in.w & 3) == 0 && (reinterpret_cast<uintptr_t>(a.in.p) & 15) == 0; }
+
+static int stem_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        cus = prop.multiProcessorCount;
+    }
+    return cus;
+}
+
 template <typename T>
 static hipError_t launch_stem_t(const ConvArgs& a, hipStream_t stream) {
     constexpr int WAVES = 4;
@@ -283,20 +402,17 @@ static hipError_t launch_stem_t(const ConvArgs& a, hipStream_t stream) {
     g.tiles_x = (a.out.w + 15) / 16;
     g.tiles_y = (a.out.h + 2 * WAVES - 1) / (2 * WAVES);
     g.num_tiles = a.out.n * g.tiles_x * g.tiles_y;
+    g.oh = a.out.h; g.ow = a.out.w;
     const size_t lds = stem_lds_bytes<T, 3, 7, 7, 2, WAVES>();
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-        cus = prop.multiProcessorCount;
-    }
+    const int cus = stem_cus();
+    if (cus == 0) return hipErrorUnknown;
     int per_cu = int((size_t(160) * 1024) / lds);
     per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
     const int slots = cus * per_cu;
     const int iters = (g.num_tiles + slots - 1) / slots;
     const int gx = (g.num_tiles + iters - 1) / iters;
-    conv_stem_kernel<T, 3, 7, 7, 2, WAVES><<<dim3(gx), dim3(64 * WAVES), lds, stream>>>(a, g);
+    if (stem_vec_ok(a)) conv_stem_kernel<T, 3, 7, 7, 2, WAVES, false, true><<<dim3(gx), dim3(64 * WAVES), lds, stream>>>(a, g);
+    else conv_stem_kernel<T, 3, 7, 7, 2, WAVES, false, false><<<dim3(gx), dim3(64 * WAVES), lds, stream>>>(a, g);
     return hipGetLastError();
 }
 
@@ -308,12 +424,51 @@ hipError_t LaunchConvStem(const ConvArgs& a_in, hipStream_t stream) {
     return (a.out.f16 || a.out.f8) ? launch_stem_t<_Float16>(a, stream) : launch_stem_t<float>(a, stream);
 }
 
+// Stem + max pool in one launch: `a` is the stem conv's argument set with `out` = the POOLED tensor (half or e4m3, NHWC).
+bool ConvStemPoolEligible(const ConvArgs& a) {
+    if (a.in.f16 || a.in.f8 || a.in.c != 3 || a.kh != 7 || a.kw != 7 || a.sh != 2 || a.sw != 2 || a.pt != 3 || a.pl != 3) return false;
+    if (a.pre_scale != nullptr || a.w == nullptr || !a.relu || a.res.p != nullptr) return false;      // the ReLU makes 0 the neutral element of the max
+    if (a.in.sw != 1 || a.in.sh != a.in.w || a.in.sc != int64_t(a.in.h) * a.in.w || a.in.sn != a.in.sc * a.in.c) return false;   // dense NCHW
+    if (!(a.out.f16 || a.out.f8) || a.out.sc != 1 || a.out.c > 64 || (a.out.c & 7) || (a.out.sw & 7) || (reinterpret_cast<uintptr_t>(a.out.p) & 15)) return false;
+    if (a.out.sh != a.out.w * a.out.sw || a.out.sn != a.out.h * a.out.sh) return false;
+    const int oh = (a.in.h + 6 - 7) / 2 + 1, ow = (a.in.w + 6 - 7) / 2 + 1;          // the conv's output
+    if (oh < 1 || ow < 1 || a.out.h != (oh + 2 - 3) / 2 + 1 || a.out.w != (ow + 2 - 3) / 2 + 1) return false;   // 3x3 / s2 / p1 windows over it
+    const int64_t in_elems = int64_t(a.in.n) * 3 * a.in.h * a.in.w, out_elems = int64_t(a.out.n) * a.out.h * a.out.w * a.out.sw;
+    return in_elems * 4 < (int64_t(1) << 31) && out_elems * 2 < (int64_t(1) << 31);
+}
+
+hipError_t LaunchConvStemPool(const ConvArgs& a_in, hipStream_t stream) {
+    if (!ConvStemPoolEligible(a_in)) return hipErrorInvalidValue;
+    ConvArgs a = a_in;
+    a.in_bytes = int64_t(a.in.n) * a.in.c * a.in.h * a.in.w * 4;
+    constexpr int WAVES = 8, PT = 7;
+    StemGeom g;
+    g.tiles_x = (a.out.w + PT - 1) / PT;
+    g.tiles_y = (a.out.h + PT - 1) / PT;
+    g.num_tiles = a.out.n * g.tiles_x * g.tiles_y;
+    g.oh = (a.in.h + 6 - 7) / 2 + 1; g.ow = (a.in.w + 6 - 7) / 2 + 1;
+    const size_t lds = stem_lds_bytes<_Float16, 3, 7, 7, 2, WAVES, true>();
+    const int cus = stem_cus();
+    if (cus == 0) return hipErrorUnknown;
+    const int per_cu = int((size_t(160) * 1024) / lds) >= 2 ? 2 : 1;
+    const int slots = cus * per_cu;
+    const int iters = (g.num_tiles + slots - 1) / slots;
+    const int gx = (g.num_tiles + iters - 1) / iters;
+    if (stem_vec_ok(a)) conv_stem_kernel<_Float16, 3, 7, 7, 2, WAVES, true, true><<<dim3(gx), dim3(64 * WAVES), lds, stream>>>(a, g);
+    else conv_stem_kernel<_Float16, 3, 7, 7, 2, WAVES, true, false><<<dim3(gx), dim3(64 * WAVES), lds, stream>>>(a, g);
+    return hipGetLastError();
+}
+
 hipError_t InitKernelsStem() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stem_kernel<_Float16, 3, 7, 7, 2, 4>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stem_kernel<float, 3, 7, 7, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               160 * 1024);
+    const void* const kernels[] = {
+        reinterpret_cast<const void*>(&conv_stem_kernel<_Float16, 3, 7, 7, 2, 4, false, false>), reinterpret_cast<const void*>(&conv_stem_kernel<_Float16, 3, 7, 7, 2, 4, false, true>),
+        reinterpret_cast<const void*>(&conv_stem_kernel<_Float16, 3, 7, 7, 2, 8, true, false>),  reinterpret_cast<const void*>(&conv_stem_kernel<_Float16, 3, 7, 7, 2, 8, true, true>),
+        reinterpret_cast<const void*>(&conv_stem_kernel<float, 3, 7, 7, 2, 4, false, false>),    reinterpret_cast<const void*>(&conv_stem_kernel<float, 3, 7, 7, 2, 4, false, true>)};
+    for (const void* k : kernels) {
+        const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 }  // namespace ie

@@ -1310,6 +1310,61 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
         }
     }
 
+    // ---- stem + max pool (fp16 / fp8): the 7x7/s2 stem conv and the 3x3/s2/p1 max pool behind it -> ONE step -------------------------------------
+    // Pattern: step i = the stem conv (algo Stem, ReLU'd, half or e4m3 output), step i + 1 = a max pool 3x3 / stride 2 / pad 1 without a prologue that
+    // reads exactly step i's output, which nothing else reads.  conv_stem_kernel<POOL> (kernels_stem.hip) pools the conv tile in LDS: the tensor
+    // between the two ops (the largest of DenseNet / ResNet) is never written.  parts = {conv, pool}; tile 1 = fused, 0 = the two launches.
+    if (precision != Precision::F32 && !env.get("IE_NO_STEM_POOL")) {
+        for (size_t i = 0; i + 1 < plan.steps.size(); ++i) {
+            const Step& c = plan.steps[i];
+            const Step& pl = plan.steps[i + 1];
+            if (c.kind != StepKind::Conv || c.algo != ConvAlgo::Stem || !c.relu || c.has_in2 || !c.parts.empty() || !(c.out.f16 || c.out.f8) || c.out.c > 64 || c.out.c % 8) continue;
+            if (pl.kind != StepKind::Pool || !pl.pool_max || pl.kh != 3 || pl.kw != 3 || pl.sh != 2 || pl.sw != 2 || pl.pt != 1 || pl.pl != 1 || pl.pb > 1 || pl.pr > 1) continue;
+            if (pl.pre_scale_off >= 0 || pl.pre_relu || pl.has_in2 || pl.in_src != int(i)) continue;
+            if (pl.in.buf != c.out.buf || pl.in.c_off != c.out.c_off || pl.in.c != c.out.c || pl.in.pitch != c.out.pitch || pl.in.h != c.out.h || pl.in.w != c.out.w) continue;
+            if (pl.out.f16 != c.out.f16 || pl.out.f8 != c.out.f8 || pl.out.nchw || pl.out.buf == c.out.buf || pl.out.buf == c.in.buf) continue;
+            if (pl.out.h != (c.out.h + 2 - 3) / 2 + 1 || pl.out.w != (c.out.w + 2 - 3) / 2 + 1) continue;
+            if (pl.out.pitch % 8 || pl.out.c_off % 8 || (pl.out.f8 && (pl.out.pitch % 16 || pl.out.c_off % 16))) continue;
+            bool ok = true;                       // the conv's output must have no other reader
+            for (size_t q = i + 2; q < plan.steps.size() && ok; ++q) {
+                const Step& t = plan.steps[q];
+                if (t.in.buf == c.out.buf || (t.has_in2 && t.in2.buf == c.out.buf)) ok = false;
+                for (const Step& tp : t.parts) if (tp.in.buf == c.out.buf || (tp.has_in2 && tp.in2.buf == c.out.buf)) ok = false;
+                if (t.out.buf == c.out.buf) break;             // recycled for another tensor: dead by then
+            }
+            for (size_t o = 0; o < out_vals.size() && ok; ++o) if (view_of(out_vals[o]).buf == c.out.buf) ok = false;
+            if (!ok) continue;
+            Step f = c;
+            f.algo = ConvAlgo::StemPool;
+            f.tile = 1;
+            f.out = pl.out;
+            f.name = c.name + " + " + pl.name;
+            f.flops = c.flops + pl.flops;
+            f.bytes = double(c.in.numel()) * c.in.esize() + double(pl.out.numel()) * pl.out.esize() + double(c.out.c) * c.kh * c.kw * c.in.c * 4;
+            f.parts = {c, pl};
+            std::vector<Step> ns;
+            ns.reserve(plan.steps.size() - 1);
+            for (size_t q = 0; q < plan.steps.size(); ++q) {
+                if (q == i + 1) continue;
+                ns.push_back(q == i ? f : plan.steps[q]);
+            }
+            auto remap = [&](int src) { return src < 0 ? src : (size_t(src) > i ? src - 1 : src); };     // i + 1 -> i, everything behind moves up
+            for (size_t q = 0; q < ns.size(); ++q) {
+                Step& st = ns[q];
+                st.idx = int(q);
+                st.in_src = remap(st.in_src);
+                st.in2_src = remap(st.in2_src);
+                for (Step& part : st.parts) { part.in_src = remap(part.in_src); part.in2_src = remap(part.in2_src); }
+            }
+            // run as two launches, the parts share the fused step's slot: one tensor scale (a max pool keeps its operand's), same producer index
+            ns[i].parts[0].idx = int(i);
+            ns[i].parts[1].idx = int(i);
+            ns[i].parts[1].in_src = int(i);
+            plan.steps = std::move(ns);
+            break;                                // one stem per graph
+        }
+    }
+
     // ---- projection shortcuts (fp8): conv3 + residual where the residual is a 1x1 projection conv -> ONE step of two GEMMs ------------------------
     // Pattern: step j = 1x1/s1 conv C with a fused residual whose producer is step i < j = a plain 1x1 conv P (any stride, no prologue, no
     // residual, no ReLU) read by nothing else.  out = relu(C(a) + P(x)) then runs as two accumulator sets of one launch (kernels_ws8.hip) and
@@ -1414,7 +1469,7 @@ static std::string json_escape(const std::string& s) {
 
 std::string PlanToJson(const Plan& p) {
     static const char* kinds[] = {"conv", "pool", "gap", "eltwise", "copy"};
-    static const char* algos[] = {"igemm_vec", "igemm_scalar", "naive", "raster3x3", "ws1x1", "ws3x3", "stem", "direct", "igemm_f8", "dense_fused", "wino3x3", "conv1x1_x6", "dense_block", "dual_f8"};
+    static const char* algos[] = {"igemm_vec", "igemm_scalar", "naive", "raster3x3", "ws1x1", "ws3x3", "stem", "direct", "igemm_f8", "dense_fused", "wino3x3", "conv1x1_x6", "dense_block", "dual_f8", "stem_pool"};
     std::ostringstream o;
     o.precision(17);
     o << "{\"inputs\":[";

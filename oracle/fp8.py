@@ -97,6 +97,16 @@ def run_plan(plan: dict, blob: np.ndarray, feeds: dict, act_scales=None, fp8: bo
             pj["_exact_out"] = True
             cv["idx"] = s["idx"]
             steps.extend([pj, cv])
+        elif s.get("parts") and s.get("algo") == "stem_pool":
+            # stem conv + max pool in one launch: the conv tile is pooled as halfs in LDS and only the pooled tensor is quantised, with the
+            # fused step's scale (conv_stem_kernel<POOL>, kernels_stem.hip)
+            cv, pl = dict(s["parts"][0]), dict(s["parts"][1])
+            if s.get("tile", 1) != 0:
+                cv["_exact_out"] = True
+                cv["_half_out"] = True
+            cv["idx"] = s["idx"]
+            pl["idx"] = s["idx"]
+            steps.extend([cv, pl])
         else:
             steps.extend(s["parts"] if s.get("parts") else [s])
     for s in steps:
@@ -168,6 +178,8 @@ def run_plan(plan: dict, blob: np.ndarray, feeds: dict, act_scales=None, fp8: bo
             y = xin
         else:
             raise NotImplementedError(s["kind"])
+        if fp8 and s.get("_half_out"):
+            y = y.astype(np.float16).astype(np.float64)
         if fp8 and vout["f8"] and not s.get("_exact_out"):
             y = quantize(y, act_scales[s["idx"]])
         elif fp8 and vout["f16"]:

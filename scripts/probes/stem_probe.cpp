@@ -1,6 +1,6 @@
 // Standalone timing of conv_stem_kernel (kernels_stem.hip) with parts of it switched off at compile time, to see what bounds it:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I gpu-ai-inference-server_amd/csrc [-DSTEM_ABLATE=n] scripts/probes/stem_probe.cpp -o build/stem_probe_n
-//   build/stem_probe_n <batch> <half: 1|0>
+//   build/stem_probe_n <batch> <1: half | 0: float | 2: half + fused max pool>
 // STEM_ABLATE: 0 whole kernel, 1 no output stores, 2 no input loads, 3 no MFMA / LDS operand reads, 4 no epilogue arithmetic and stores.
 #include "../../gpu-ai-inference-server_amd/csrc/kernels_stem.hip"
 
@@ -11,8 +11,8 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s failed: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 int main(int argc, char** argv) {
-    const int B = argc > 1 ? atoi(argv[1]) : 128, half = argc > 2 ? atoi(argv[2]) : 1;
-    const int H = 224, W = 224, OH = 112, OW = 112, C = 64;
+    const int B = argc > 1 ? atoi(argv[1]) : 128, mode = argc > 2 ? atoi(argv[2]) : 1, half = mode != 0, pool = mode == 2;
+    const int H = 224, W = 224, OH = pool ? 56 : 112, OW = pool ? 56 : 112, C = 64;
     float *x, *w, *bias;
     void* y;
     const size_t xin = size_t(B) * 3 * H * W, yout = size_t(B) * OH * OW * C;
@@ -28,12 +28,13 @@ int main(int argc, char** argv) {
     a.out.f16 = half;
     a.w = w; a.bias = bias; a.kh = 7; a.kw = 7; a.sh = 2; a.sw = 2; a.pt = 3; a.pl = 3; a.relu = 1;
     CK(ie::InitKernelsStem());
-    if (!ie::ConvStemEligible(a)) { printf("not eligible\n"); return 2; }
-    for (int i = 0; i < 3; ++i) CK(ie::LaunchConvStem(a, nullptr));
+    if (!(pool ? ie::ConvStemPoolEligible(a) : ie::ConvStemEligible(a))) { printf("not eligible\n"); return 2; }
+    auto launch = [&]() { return pool ? ie::LaunchConvStemPool(a, nullptr) : ie::LaunchConvStem(a, nullptr); };
+    for (int i = 0; i < 3; ++i) CK(launch());
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     CK(hipEventRecord(e0, nullptr));
-    for (int i = 0; i < 20; ++i) CK(ie::LaunchConvStem(a, nullptr));
+    for (int i = 0; i < 20; ++i) CK(launch());
     CK(hipEventRecord(e1, nullptr));
     CK(hipDeviceSynchronize());
     float ms;
@@ -42,6 +43,6 @@ int main(int argc, char** argv) {
 #define STEM_ABLATE 0
 #endif
     const double bytes = xin * 4.0 + yout * (half ? 2.0 : 4.0);
-    printf("ablate %d  B=%d %s: %.1f us per launch, %.2f TB/s of algorithmic bytes\n", STEM_ABLATE, B, half ? "half" : "float", ms * 50.f, bytes / (ms / 20 * 1e-3) / 1e12);
+    printf("ablate %d  B=%d %s: %.1f us per launch, %.2f TB/s of algorithmic bytes\n", STEM_ABLATE, B, pool ? "half + pool" : (half ? "half" : "float"), ms * 50.f, bytes / (ms / 20 * 1e-3) / 1e12);
     return 0;
 }

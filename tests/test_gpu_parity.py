@@ -906,6 +906,39 @@ def test_fp16_dense_block_chain_kernel(tmp_path, batch, image, stem, blocks, ban
     assert e < F16_RTOL and e0 < F16_RTOL and d < F16_RTOL
 
 
+@pytest.mark.parametrize("batch,image,stem", [(1, 32, 64), (3, 50, 32), (2, 62, 64), (5, 224, 64), (2, 230, 16), (9, 112, 48)])
+def test_fp16_stem_and_max_pool_in_one_launch(tmp_path, batch, image, stem):
+    """conv_stem_kernel<POOL> (kernels_stem.hip): the 7x7/s2 stem conv and the 3x3/s2/p1 max pool behind it as ONE step (plan algo "stem_pool"), the
+    conv tile pooled in LDS.  Even and odd conv / pooled sizes (ragged 7 x 7 pooled tiles, windows hanging over every image edge), 16 ... 64 stem
+    channels: bit-identical logits to the same plan run as two launches (IE_NO_STEM_POOL=1: the same MFMA sequence, the same halfs, max is exact) and
+    within F16_RTOL of the float64 oracle."""
+    mb = models.densenet(batch, growth=16, blocks=(2, 2), stem=stem, image=image, classes=24, seed=57)
+    path = models.write_repo(str(tmp_path), "stempool", mb)
+    x = models.synthetic_input((batch, 3, image, image), stream="stempool")
+    ref = O.run(O.load_model(mb), {"data_0": x}, dtype=np.float64)["fc6_1"].reshape(batch, 24)
+
+    def go():
+        m = B.CreateModel(path, "stempool")
+        try:
+            y = infer(m, "", "data_0", x, "fc6_1", [batch, 24, 1, 1])[0].reshape(batch, 24).copy()
+            din, _ = B.Prepare(m, [[batch, 3, image, image]], 1)
+            B.CopyToDevice(m, din[0], x)
+            B.RunPrepared(m, 1, True)
+            return y, [p_["kernel"] for p_ in B.Profile(m, 1)], B.DescribeModel(path, batch)["plan"]
+        finally:
+            m.Destroy()
+    y, kern, plan = _run_with_env(_f16_env(IE_AUTOTUNE="0"), go)
+    y0, kern0, plan0 = _run_with_env(_f16_env(IE_AUTOTUNE="0", IE_NO_STEM_POOL="1"), go)
+    s0 = plan["steps"][0]
+    conv_hw = (image + 6 - 7) // 2 + 1
+    assert s0["algo"] == "stem_pool" and s0["tile"] == 1 and s0["out"]["h"] == (conv_hw - 1) // 2 + 1 and plan0["steps"][0]["algo"] == "stem" and plan0["steps"][1]["kind"] == "pool"
+    assert kern[0].startswith("conv_stem_kernel<f16,pool") and kern0[0] == "conv_stem_kernel<f16>" and kern0[1].startswith("pool_kernel") and len(kern) == len(kern0) - 1, (kern[:2], kern0[:3])
+    e = rel_err(y, ref)
+    print(f"stem + pool B={batch} image={image} ({conv_hw} -> {s0['out']['h']}) stem={stem}: rel err {e:.2e}, max |one launch - two launches| {np.abs(y - y0).max():.1e}")
+    assert np.array_equal(y, y0)
+    assert e < F16_RTOL
+
+
 def test_fp16_densenet121_fixture_and_batch_independence(densenet_repo, tmp_path):
     """DenseNet-121 in fp16 mode selected through config.json ("precision": "fp16"), B=2 against the float64 fixture and the
     B=32 size-independent property (each image's logits equal that image run alone, up to summation-order rounding)."""

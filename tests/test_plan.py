@@ -128,10 +128,17 @@ def test_fp16_plan_keeps_graph_io_fp32(densenet_repo, monkeypatch):
     assert p["precision"] == "fp16"
     assert not p["inputs"][0]["view"]["f16"] and not p["outputs"][0]["view"]["f16"]
     convs = [s for s in p["steps"] if s["kind"] == "conv"]
-    assert convs[0]["algo"] == "stem" and not convs[0]["in"]["f16"] and convs[0]["out"]["f16"]      # fp32 NCHW in, half NHWC out
+    # fp32 NCHW in, half NHWC out -- and the max pool behind the stem rides in the same launch: the 112 x 112 x 64 tensor never exists
+    assert convs[0]["algo"] == "stem_pool" and not convs[0]["in"]["f16"] and convs[0]["out"]["f16"] and (convs[0]["out"]["h"], convs[0]["out"]["w"]) == (56, 56)
+    assert [q["kind"] for q in convs[0]["parts"]] == ["conv", "pool"] and convs[0]["parts"][0]["algo"] == "stem" and convs[0]["parts"][1]["max"]
+    assert not [s for s in p["steps"] if s["kind"] == "pool" and s["max"]] and p["steps"][1]["in_src"] == 0
     assert all(s["in"]["f16"] and s["out"]["f16"] for s in convs[1:-1])
     assert convs[-1]["in"]["f16"] and not convs[-1]["out"]["f16"]                                    # classifier writes fp32 logits
-    assert 45e6 < sum(s["bytes"] for s in p["steps"]) / 32 < 50e6                                    # 47.6 MB/img + weights/32 (minus the swapped transitions)
+    assert 42e6 < sum(s["bytes"] for s in p["steps"]) / 32 < 47e6                                    # 47.6 MB/img + weights/32, minus the swapped transitions and the stem tensor (2 x 1.6 MB)
+    monkeypatch.setenv("IE_NO_STEM_POOL", "1")
+    p2 = B.DescribeModel(os.path.join(densenet_repo, "densenet_onnx", "1"), 32)["plan"]
+    assert p2["steps"][0]["algo"] == "stem" and p2["steps"][1]["kind"] == "pool" and len(p2["steps"]) == len(p["steps"]) + 1
+    monkeypatch.delenv("IE_NO_STEM_POOL")
     assert p["activation_bytes"] < 170e6                                                             # vs 300 MB in fp32
     monkeypatch.setenv("IE_PRECISION", "fp32")
     p32 = B.DescribeModel(os.path.join(densenet_repo, "densenet_onnx", "1"), 32)["plan"]
@@ -271,7 +278,8 @@ def test_fp8_plan_structure_and_rejections(tmp_path, densenet_repo, monkeypatch)
     p = B.DescribeModel(path, 4)["plan"]
     assert p["precision"] == "fp8"
     convs = [s for s in p["steps"] if s["kind"] == "conv"]
-    assert convs[0]["algo"] == "stem" and not convs[0]["in"]["f8"] and convs[0]["out"]["f8"]
+    assert convs[0]["algo"] == "stem_pool" and not convs[0]["in"]["f8"] and convs[0]["out"]["f8"] and len(convs[0]["parts"]) == 2
+    assert all(q["idx"] == 0 for q in convs[0]["parts"]) and convs[0]["parts"][1]["in_src"] == 0          # run as two launches they share the fused step's scale
     # 53 convs + the classifier; the projection shortcut of stage 1 and the block's last 1x1 are ONE step (two GEMMs of one launch:
     # the shortcut tensor is never written), the strided projections of stages 2-4 keep their own step
     dual = [s for s in convs if s["algo"] == "dual_f8"]
