@@ -119,7 +119,7 @@ void load_tune_file(const std::string& path, std::map<std::vector<int64_t>, std:
         int t = -1, sp = 0;
         if (ok && (is >> t >> sp) && ((t >= 0 && t < kNumIgemmTiles) || (t >= 100 && t < 100 + kNumConvRasterTiles) || (t >= 200 && t < 200 + kNumConvWs32Tiles) ||
                                        (t >= 300 && t < 300 + kNumConvWs3Tiles) || (t >= 400 && t < 400 + kNumConvDirectTiles) || (t >= 500 && t < 500 + kNumConvWinoTiles) || (t >= 600 && t < 600 + kNumConvX6Tiles)) &&
-            sp >= 1 && sp <= 64 && key.size() >= 17)
+            sp >= 1 && sp <= 64 && key.size() >= 6)          // (the fused steps have short signatures: stem + pool 7 numbers, dense block 10, dual 9)
             cache[key] = {t, sp};
     }
 }
@@ -830,7 +830,7 @@ void DeviceModel::Autotune(PlanInstance& pi, size_t nsteps, bool allow_search) {
             }
             if (s.algo == ConvAlgo::StemPool) {
                 // fused vs the two launches: one timed choice (tile 1 / 0), cached like the others
-                std::vector<int64_t> keys = {s.in.n, s.in.h, s.in.w, s.out.c, s.out.pitch, s.out.f8 ? 2 : 1, int64_t(ConvAlgo::StemPool)};
+                std::vector<int64_t> keys = {s.in.n, s.in.h, s.in.w, s.out.c, s.out.pitch, s.out.f8 ? 2 : (s.out.f16 ? 1 : 0), int64_t(ConvAlgo::StemPool)};
                 int choice = -1;
                 {
                     std::lock_guard<std::mutex> g(w_->tune_mu);
@@ -1553,7 +1553,7 @@ static std::string kernel_label(const Step& s) {
                                              : s.in.f16 ? "conv_direct_kernel<f16,t" : "conv_direct_kernel<f32,t";
                 return std::string(k) + std::to_string(s.tile) + ">";
             }
-            if (s.algo == ConvAlgo::StemPool) return s.tile != 0 ? (s.out.f8 ? "conv_stem_kernel<f16,pool,e4m3 out>" : "conv_stem_kernel<f16,pool>") : "stem + pool (2 launches)";
+            if (s.algo == ConvAlgo::StemPool) return s.tile != 0 ? (s.out.f8 ? "conv_stem_kernel<f16,pool,e4m3 out>" : (s.out.f16 ? "conv_stem_kernel<f16,pool>" : "conv_stem_kernel<f32,pool>")) : "stem + pool (2 launches)";
             if (s.algo == ConvAlgo::Stem) return s.out.f8 ? "conv_stem_kernel<f16,e4m3 out>" : (s.out.f16 ? "conv_stem_kernel<f16>" : "conv_stem_kernel<f32>");
             if (s.algo == ConvAlgo::Ws1x1) return std::string(s.in.f16 ? "conv1x1_ws_f16_kernel<t" : "conv1x1_ws_f32_kernel<t") + std::to_string(s.tile) + ">";
             if (s.algo == ConvAlgo::Ws3x3) return "conv3x3_ws_f16_kernel<t" + std::to_string(s.tile) + ">";

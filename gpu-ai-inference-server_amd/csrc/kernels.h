@@ -128,7 +128,7 @@ hipError_t InitKernelsDirect();
 // half arithmetic + half output in fp16 mode, fp32 otherwise.
 bool ConvStemEligible(const ConvArgs& a);
 hipError_t LaunchConvStem(const ConvArgs& a, hipStream_t stream);
-// The stem AND the 3x3 / stride 2 / pad 1 max pool behind it in one launch (fp16 / fp8 modes): `a` is the stem's argument set with out = the POOLED tensor.
+// The stem AND the 3x3 / stride 2 / pad 1 max pool behind it in one launch: `a` is the stem's argument set with out = the POOLED tensor.
 bool ConvStemPoolEligible(const ConvArgs& a);
 hipError_t LaunchConvStemPool(const ConvArgs& a, hipStream_t stream);
 hipError_t InitKernelsStem();

@@ -10,9 +10,9 @@
 //   fp32 mode: float window and weights, v_mfma_f32_32x32x2_f32 (4 MFMAs per 16-byte weight fragment), float NHWC output.
 // D = W x A^T: a lane owns one output pixel and quads of channels (16-byte stores).
 //
-// POOL variant (fp16 / fp8 modes): the 3x3 / stride 2 / pad 1 max pool that follows the stem in DenseNet and ResNet runs in the same launch.  A
+// POOL variant: the 3x3 / stride 2 / pad 1 max pool that follows the stem in DenseNet and ResNet runs in the same launch.  A
 // workgroup of 8 waves owns 7 x 7 POOLED pixels = a 15 x 15 patch of conv outputs inside its 16 x 16 tile (origin 2 * 7 * t - 1: one halo row / column
-// recomputed per side, 1.31x the conv work, which is cheap in half precision); the ReLU'd conv tile goes to LDS as halfs (zeros outside the image:
+// recomputed per side, 1.31x the conv work); the ReLU'd conv tile goes to LDS as halfs (zeros outside the image:
 // after a ReLU they never win a max), a barrier, and 49 x Cout/8 threads each take the max of nine 16-byte reads and store 8 channels.  The
 // 112 x 112 x 64 tensor between the two ops -- the largest of the whole network -- is never written or read.
 #include <hip/hip_runtime.h>
@@ -38,12 +38,14 @@ struct StemGeom {
     int oh, ow;                       // conv output size (== the output tensor's unless the max pool is fused)
 };
 
-constexpr int kStemPoolPitch = 72;    // halfs per conv pixel in the POOL variant's LDS tile: 144 B, 16-byte aligned, 4 banks apart
+// elements per conv pixel in the POOL variant's LDS tile: 16-byte aligned rows, consecutive pixels 4 banks apart (halfs: 144 B, floats: 272 B)
+template <typename T> constexpr int stem_pool_pitch() { return sizeof(T) == 2 ? 72 : 68; }
 
 // T = _Float16 (fp16 mode) or float (fp32 mode)
 template <typename T, int CIN, int KH, int KW, int S, int WAVES, bool POOL, bool VEC>
 __global__ __launch_bounds__(64 * WAVES) void conv_stem_kernel(const ConvArgs a, const StemGeom g) {
-    static_assert(!POOL || (sizeof(T) == 2 && WAVES == 8 && S == 2), "the fused max pool: half arithmetic, 16 x 16 conv tiles");
+    static_assert(!POOL || (WAVES == 8 && S == 2), "the fused max pool: 16 x 16 conv tiles");
+    constexpr int CP = stem_pool_pitch<T>();
     constexpr bool HALF = sizeof(T) == 2;
     constexpr int NT = 64 * WAVES, TW = 16, TH = 2 * WAVES;
     constexpr int G = CIN * KH;                          // (c, ky) groups of 8 k each
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_stem_kernel(const ConvArgs a,
     // window row pitch.  Lanes 16-31 of a row block sit one output row (S window rows) below lanes 0-15; with halfs the pitch
     // puts them 16 banks away (S*WP*2 == 64 mod 128: conflict-free 4-byte reads).  With floats the lanes are 8 bytes apart and a
     // 2-way conflict is unavoidable (and irrelevant beside 64-cycle MFMAs), so the pitch is just the padded width.
-    constexpr int WP = HALF ? (S == 2 ? 48 : 96) : 40;
+    constexpr int WP = HALF ? (S == 2 ? 48 : 96) : (POOL ? 44 : 40);
     static_assert(WP >= WCOLS, "window pitch too small");
     constexpr int BP = KP + (HALF ? 8 : 4);              // weight row pitch (16-byte units odd)
     constexpr int WIN = CIN * WROWS * WP;
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_stem_kernel(const ConvArgs a,
     T* const sWt = reinterpret_cast<T*>(smem_stem);      // [64][BP]
     T* const sWin = sWt + 64 * BP;                       // [2][CIN][WROWS][WP]
     float* const sBias = reinterpret_cast<float*>(sWin + 2 * WIN);   // [64]
-    _Float16* const sC = reinterpret_cast<_Float16*>(sBias + 64);    // POOL: [TH * TW][kStemPoolPitch] conv tile
+    T* const sC = reinterpret_cast<T*>(sBias + 64);                  // POOL: [TH * TW][CP] conv tile
     constexpr int PT = (TH - 2) / 2;                                 // POOL: pooled rows / columns per tile
 
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_stem_kernel(const ConvArgs a,
         const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
         const int cy = ty * 2 * PT - 1 + oyl, cx = tx * 2 * PT - 1 + oxl;
         const bool valid = unsigned(cy) < unsigned(OH) && unsigned(cx) < unsigned(OW);
-        _Float16* const dst = sC + (oyl * TW + oxl) * kStemPoolPitch;
+        T* const dst = sC + (oyl * TW + oxl) * CP;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             float v[16];
@@ -287,14 +289,19 @@ __global__ __launch_bounds__(64 * WAVES) void conv_stem_kernel(const ConvArgs a,
                     acc[j][4 * gq + q] = 0.f;
                 }
             }
+            if constexpr (HALF) {
 #pragma unroll
-            for (int gp = 0; gp < 2; ++gp) {
-                const h4 qa = {_Float16(v[8 * gp + 0]), _Float16(v[8 * gp + 1]), _Float16(v[8 * gp + 2]), _Float16(v[8 * gp + 3])};
-                const h4 qb = {_Float16(v[8 * gp + 4]), _Float16(v[8 * gp + 5]), _Float16(v[8 * gp + 6]), _Float16(v[8 * gp + 7])};
-                const u32x2 xa = __builtin_bit_cast(u32x2, qa), xb = __builtin_bit_cast(u32x2, qb);
-                const auto s0 = __builtin_amdgcn_permlane32_swap(xa[0], xb[0], false, false);
-                const auto s1 = __builtin_amdgcn_permlane32_swap(xa[1], xb[1], false, false);
-                *reinterpret_cast<u32x4*>(dst + j * 32 + 8 * (2 * gp + hh)) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                for (int gp = 0; gp < 2; ++gp) {
+                    const h4 qa = {_Float16(v[8 * gp + 0]), _Float16(v[8 * gp + 1]), _Float16(v[8 * gp + 2]), _Float16(v[8 * gp + 3])};
+                    const h4 qb = {_Float16(v[8 * gp + 4]), _Float16(v[8 * gp + 5]), _Float16(v[8 * gp + 6]), _Float16(v[8 * gp + 7])};
+                    const u32x2 xa = __builtin_bit_cast(u32x2, qa), xb = __builtin_bit_cast(u32x2, qb);
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(xa[0], xb[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(xa[1], xb[1], false, false);
+                    *reinterpret_cast<u32x4*>(dst + j * 32 + 8 * (2 * gp + hh)) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                }
+            } else {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) *reinterpret_cast<f32x4*>(dst + j * 32 + 8 * gq + 4 * hh) = f32x4{v[4 * gq], v[4 * gq + 1], v[4 * gq + 2], v[4 * gq + 3]};
             }
         }
     };
@@ -308,26 +315,38 @@ __global__ __launch_bounds__(64 * WAVES) void conv_stem_kernel(const ConvArgs a,
         const int pp = tid / cgs, cg = tid - pp * cgs;
         const int ply = pp / PT, plx = pp - ply * PT;
         const int py = ty * PT + ply, px = tx * PT + plx;
-        const _Float16* const src = sC + ((2 * ply) * TW + 2 * plx) * kStemPoolPitch + cg * 8;
-        h8 m = *reinterpret_cast<const h8*>(src);
-#pragma unroll
-        for (int d = 1; d < 9; ++d) m = __builtin_elementwise_max(m, *reinterpret_cast<const h8*>(src + ((d / 3) * TW + (d % 3)) * kStemPoolPitch));
+        const T* const src = sC + ((2 * ply) * TW + 2 * plx) * CP + cg * 8;
         const bool ok = py < a.out.h && px < a.out.w;
         const unsigned off = ok ? unsigned((((b * a.out.h + py) * a.out.w + px) * opitch + cg * 8) * esz) : OOB;
-        if (a.out.f8) {
-            unsigned d[2];
+        if constexpr (HALF) {
+            h8 m = *reinterpret_cast<const h8*>(src);
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                float q4[4];
+            for (int d = 1; d < 9; ++d) m = __builtin_elementwise_max(m, *reinterpret_cast<const h8*>(src + ((d / 3) * TW + (d % 3)) * CP));
+            if (a.out.f8) {
+                unsigned d[2];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) q4[e] = __builtin_fminf(float(m[4 * q + e]) * a.out_qscale, 448.f);
-                int pk = __builtin_amdgcn_cvt_pk_fp8_f32(q4[0], q4[1], 0, false);
-                pk = __builtin_amdgcn_cvt_pk_fp8_f32(q4[2], q4[3], pk, true);
-                d[q] = unsigned(pk);
+                for (int q = 0; q < 2; ++q) {
+                    float q4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) q4[e] = __builtin_fminf(float(m[4 * q + e]) * a.out_qscale, 448.f);
+                    int pk = __builtin_amdgcn_cvt_pk_fp8_f32(q4[0], q4[1], 0, false);
+                    pk = __builtin_amdgcn_cvt_pk_fp8_f32(q4[2], q4[3], pk, true);
+                    d[q] = unsigned(pk);
+                }
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{d[0], d[1]}, rs_out, off, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, m), rs_out, off, 0, 0);
             }
-            __builtin_amdgcn_raw_buffer_store_b64(u32x2{d[0], d[1]}, rs_out, off, 0, 0);
         } else {
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, m), rs_out, off, 0, 0);
+            f32x4 m0 = *reinterpret_cast<const f32x4*>(src), m1 = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+            for (int d = 1; d < 9; ++d) {
+                const T* const q = src + ((d / 3) * TW + (d % 3)) * CP;
+                m0 = __builtin_elementwise_max(m0, *reinterpret_cast<const f32x4*>(q));
+                m1 = __builtin_elementwise_max(m1, *reinterpret_cast<const f32x4*>(q + 4));
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, m0), rs_out, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, m1), rs_out, ok ? off + 16u : OOB, 0, 0);
         }
     };
 
@@ -363,9 +382,9 @@ static size_t stem_lds_bytes() {
     constexpr int TH = 2 * WAVES, G = CIN * KH;
     constexpr int KP = HALF ? ((G + 1) / 2) * 16 : G * 8;
     constexpr int WROWS = S * (TH - 1) + KH;
-    constexpr int WP = HALF ? (S == 2 ? 48 : 96) : 40;
+    constexpr int WP = HALF ? (S == 2 ? 48 : 96) : (POOL ? 44 : 40);
     constexpr int BP = KP + (HALF ? 8 : 4);
-    return size_t(64 * BP + 2 * CIN * WROWS * WP) * sizeof(T) + 64 * sizeof(float) + (POOL ? size_t(TH * 16 * kStemPoolPitch) * 2 : 0);
+    return size_t(64 * BP + 2 * CIN * WROWS * WP) * sizeof(T) + 64 * sizeof(float) + (POOL ? size_t(TH * 16 * stem_pool_pitch<T>()) * sizeof(T) : 0);
 }
 
 bool ConvStemEligible(const ConvArgs& a) {
@@ -424,46 +443,52 @@ hipError_t LaunchConvStem(const ConvArgs& a_in, hipStream_t stream) {
     return (a.out.f16 || a.out.f8) ? launch_stem_t<_Float16>(a, stream) : launch_stem_t<float>(a, stream);
 }
 
-// Stem + max pool in one launch: `a` is the stem conv's argument set with `out` = the POOLED tensor (half or e4m3, NHWC).
+// Stem + max pool in one launch: `a` is the stem conv's argument set with `out` = the POOLED tensor (float, half or e4m3, NHWC).
 bool ConvStemPoolEligible(const ConvArgs& a) {
     if (a.in.f16 || a.in.f8 || a.in.c != 3 || a.kh != 7 || a.kw != 7 || a.sh != 2 || a.sw != 2 || a.pt != 3 || a.pl != 3) return false;
     if (a.pre_scale != nullptr || a.w == nullptr || !a.relu || a.res.p != nullptr) return false;      // the ReLU makes 0 the neutral element of the max
     if (a.in.sw != 1 || a.in.sh != a.in.w || a.in.sc != int64_t(a.in.h) * a.in.w || a.in.sn != a.in.sc * a.in.c) return false;   // dense NCHW
-    if (!(a.out.f16 || a.out.f8) || a.out.sc != 1 || a.out.c > 64 || (a.out.c & 7) || (a.out.sw & 7) || (reinterpret_cast<uintptr_t>(a.out.p) & 15)) return false;
+    if (a.out.sc != 1 || a.out.c > 64 || (a.out.c & 7) || (a.out.sw & 7) || (reinterpret_cast<uintptr_t>(a.out.p) & 15)) return false;
     if (a.out.sh != a.out.w * a.out.sw || a.out.sn != a.out.h * a.out.sh) return false;
     const int oh = (a.in.h + 6 - 7) / 2 + 1, ow = (a.in.w + 6 - 7) / 2 + 1;          // the conv's output
     if (oh < 1 || ow < 1 || a.out.h != (oh + 2 - 3) / 2 + 1 || a.out.w != (ow + 2 - 3) / 2 + 1) return false;   // 3x3 / s2 / p1 windows over it
     const int64_t in_elems = int64_t(a.in.n) * 3 * a.in.h * a.in.w, out_elems = int64_t(a.out.n) * a.out.h * a.out.w * a.out.sw;
-    return in_elems * 4 < (int64_t(1) << 31) && out_elems * 2 < (int64_t(1) << 31);
+    return in_elems * 4 < (int64_t(1) << 31) && out_elems * 4 < (int64_t(1) << 31);
 }
 
-hipError_t LaunchConvStemPool(const ConvArgs& a_in, hipStream_t stream) {
-    if (!ConvStemPoolEligible(a_in)) return hipErrorInvalidValue;
-    ConvArgs a = a_in;
-    a.in_bytes = int64_t(a.in.n) * a.in.c * a.in.h * a.in.w * 4;
+template <typename T>
+static hipError_t launch_stem_pool_t(const ConvArgs& a, hipStream_t stream) {
     constexpr int WAVES = 8, PT = 7;
     StemGeom g;
     g.tiles_x = (a.out.w + PT - 1) / PT;
     g.tiles_y = (a.out.h + PT - 1) / PT;
     g.num_tiles = a.out.n * g.tiles_x * g.tiles_y;
     g.oh = (a.in.h + 6 - 7) / 2 + 1; g.ow = (a.in.w + 6 - 7) / 2 + 1;
-    const size_t lds = stem_lds_bytes<_Float16, 3, 7, 7, 2, WAVES, true>();
+    const size_t lds = stem_lds_bytes<T, 3, 7, 7, 2, WAVES, true>();
     const int cus = stem_cus();
     if (cus == 0) return hipErrorUnknown;
     const int per_cu = int((size_t(160) * 1024) / lds) >= 2 ? 2 : 1;
     const int slots = cus * per_cu;
     const int iters = (g.num_tiles + slots - 1) / slots;
     const int gx = (g.num_tiles + iters - 1) / iters;
-    if (stem_vec_ok(a)) conv_stem_kernel<_Float16, 3, 7, 7, 2, WAVES, true, true><<<dim3(gx), dim3(64 * WAVES), lds, stream>>>(a, g);
-    else conv_stem_kernel<_Float16, 3, 7, 7, 2, WAVES, true, false><<<dim3(gx), dim3(64 * WAVES), lds, stream>>>(a, g);
+    if (stem_vec_ok(a)) conv_stem_kernel<T, 3, 7, 7, 2, WAVES, true, true><<<dim3(gx), dim3(64 * WAVES), lds, stream>>>(a, g);
+    else conv_stem_kernel<T, 3, 7, 7, 2, WAVES, true, false><<<dim3(gx), dim3(64 * WAVES), lds, stream>>>(a, g);
     return hipGetLastError();
+}
+
+hipError_t LaunchConvStemPool(const ConvArgs& a_in, hipStream_t stream) {
+    if (!ConvStemPoolEligible(a_in)) return hipErrorInvalidValue;
+    ConvArgs a = a_in;
+    a.in_bytes = int64_t(a.in.n) * a.in.c * a.in.h * a.in.w * 4;
+    return (a.out.f16 || a.out.f8) ? launch_stem_pool_t<_Float16>(a, stream) : launch_stem_pool_t<float>(a, stream);
 }
 
 hipError_t InitKernelsStem() {
     const void* const kernels[] = {
         reinterpret_cast<const void*>(&conv_stem_kernel<_Float16, 3, 7, 7, 2, 4, false, false>), reinterpret_cast<const void*>(&conv_stem_kernel<_Float16, 3, 7, 7, 2, 4, false, true>),
         reinterpret_cast<const void*>(&conv_stem_kernel<_Float16, 3, 7, 7, 2, 8, true, false>),  reinterpret_cast<const void*>(&conv_stem_kernel<_Float16, 3, 7, 7, 2, 8, true, true>),
-        reinterpret_cast<const void*>(&conv_stem_kernel<float, 3, 7, 7, 2, 4, false, false>),    reinterpret_cast<const void*>(&conv_stem_kernel<float, 3, 7, 7, 2, 4, false, true>)};
+        reinterpret_cast<const void*>(&conv_stem_kernel<float, 3, 7, 7, 2, 4, false, false>),    reinterpret_cast<const void*>(&conv_stem_kernel<float, 3, 7, 7, 2, 4, false, true>),
+        reinterpret_cast<const void*>(&conv_stem_kernel<float, 3, 7, 7, 2, 8, true, false>),     reinterpret_cast<const void*>(&conv_stem_kernel<float, 3, 7, 7, 2, 8, true, true>)};
     for (const void* k : kernels) {
         const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;

@@ -53,8 +53,11 @@ struct Ws8Geom {
     int sh_ohw, sh_ow;
 };
 
-template <int TN, int WAVES, bool DUAL>
+// STR: the (single) input is read through the conv's stride (ResNet's strided projection shortcuts): output pixel -> input pixel by the same
+// multiply-shift division as DUAL's second input.
+template <int TN, int WAVES, bool DUAL, bool STR = false>
 __global__ __launch_bounds__(64 * WAVES) void conv1x1_ws_f8_kernel(const ConvArgs a, const Ws8Geom g) {
+    static_assert(!(DUAL && STR), "the strided variant has one input");
     constexpr int NT = 64 * WAVES, BN = 32 * TN, D = kRing8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_w8[];
     const int K1 = a.in.c, K2 = DUAL ? a.in2.c : 0;
@@ -85,7 +88,16 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_ws_f8_kernel(const ConvArg
     auto row_offsets = [&](int rb) {
         const int m = rb * 32 + r;
         const bool ok = rb < nrb && m < M;
-        off1_l = ok ? unsigned(m * ipitch + hh * 16) : kOOB8;
+        if constexpr (STR) {
+            const unsigned um = ok ? unsigned(m) : 0u;
+            const int b = int((static_cast<unsigned long long>(um) * g.m_ohw) >> g.sh_ohw);
+            const int rem = int(um) - b * g.ohw;
+            const int oy = int((static_cast<unsigned long long>(unsigned(rem)) * g.m_ow) >> g.sh_ow);
+            const int ox = rem - oy * g.ow;
+            off1_l = ok ? unsigned(b * int(a.in.sn) + oy * a.sh * int(a.in.sh) + ox * a.sw * ipitch + hh * 16) : kOOB8;
+        } else {
+            off1_l = ok ? unsigned(m * ipitch + hh * 16) : kOOB8;
+        }
         if constexpr (DUAL) {
             // output pixel m -> (image b, oy, ox) -> the projection's input pixel (b, oy * sh, ox * sw)
             const unsigned um = ok ? unsigned(m) : 0u;
@@ -263,13 +275,15 @@ bool ConvWs8Eligible(const ConvArgs& a, int tile) {
     if (tile < 0 || tile >= kNumConvWs8Tiles) return false;
     const bool dual = a.in2.p != nullptr;
     if (!ws8_tensor_ok(a.in) || !a.out.f8 || a.w8 == nullptr || a.escale == nullptr || a.pre_scale != nullptr) return false;
-    if (a.kh != 1 || a.kw != 1 || a.sh != 1 || a.sw != 1 || a.pt != 0 || a.pl != 0 || a.in.h != a.out.h || a.in.w != a.out.w || a.in.n != a.out.n) return false;
+    if (a.kh != 1 || a.kw != 1 || a.sh < 1 || a.sw < 1 || a.pt != 0 || a.pl != 0 || a.in.n != a.out.n) return false;
+    if (a.out.h != (a.in.h - 1) / a.sh + 1 || a.out.w != (a.in.w - 1) / a.sw + 1) return false;
+    if ((a.sh != 1 || a.sw != 1) && dual) return false;                                                       // a strided first input: the single-GEMM variant only
     if (a.in.sh != a.in.w * a.in.sw || a.in.sn != a.in.h * a.in.sh) return false;                          // pixels at a constant pitch
     if (a.out.sc != 1 || (a.out.c & 15) || (a.out.sw & 15) || (reinterpret_cast<uintptr_t>(a.out.p) & 15)) return false;
     if (a.out.sh != a.out.w * a.out.sw || a.out.sn != a.out.h * a.out.sh) return false;
     if ((reinterpret_cast<uintptr_t>(a.w8) & 15)) return false;
     const int64_t M = int64_t(a.out.n) * a.out.h * a.out.w;
-    if (M * a.in.sw >= (int64_t(1) << 31) || M * a.out.sw >= (int64_t(1) << 31) || int64_t(a.out.c) * a.in.c >= (int64_t(1) << 31)) return false;
+    if (int64_t(a.in.n) * a.in.sn >= (int64_t(1) << 31) || M * a.out.sw >= (int64_t(1) << 31) || int64_t(a.out.c) * a.in.c >= (int64_t(1) << 31)) return false;
     if (a.res.p != nullptr) {
         if (!a.res.f8 || a.res.sc != 1 || (a.res.sw & 15) || (reinterpret_cast<uintptr_t>(a.res.p) & 15) || a.res.c != a.out.c) return false;
         if (a.res.sh != a.res.w * a.res.sw || a.res.sn != a.res.h * a.res.sh || a.res.n != a.out.n || a.res.h != a.out.h || a.res.w != a.out.w) return false;
@@ -295,7 +309,7 @@ static void magic_div8(unsigned d, unsigned long long* m, int* sh) {      // flo
     *m = ((1ull << (31 + L)) / d) + 1;
 }
 
-template <int TN, int WAVES, bool DUAL>
+template <int TN, int WAVES, bool DUAL, bool STR = false>
 static hipError_t launch_ws8_t(const ConvArgs& a, hipStream_t stream) {
     const int64_t M = int64_t(a.out.n) * a.out.h * a.out.w;
     const int nrb = int((M + 31) / 32);
@@ -321,7 +335,7 @@ static hipError_t launch_ws8_t(const ConvArgs& a, hipStream_t stream) {
     g.ow = a.out.w;
     magic_div8(unsigned(g.ohw), &g.m_ohw, &g.sh_ohw);
     magic_div8(unsigned(g.ow), &g.m_ow, &g.sh_ow);
-    conv1x1_ws_f8_kernel<TN, WAVES, DUAL><<<dim3(gx, gy), dim3(64 * WAVES), lds, stream>>>(a, g);
+    conv1x1_ws_f8_kernel<TN, WAVES, DUAL, STR><<<dim3(gx, gy), dim3(64 * WAVES), lds, stream>>>(a, g);
     return hipGetLastError();
 }
 
@@ -331,6 +345,16 @@ hipError_t LaunchConvWs1x1F8(const ConvArgs& a_in, int tile, hipStream_t stream)
     a.in_bytes = int64_t(a.in.n - 1) * a.in.sn + int64_t(a.in.h - 1) * a.in.sh + int64_t(a.in.w - 1) * a.in.sw + a.in.c;
     const bool dual = a.in2.p != nullptr;
     if (dual) a.in2_bytes = int64_t(a.in2.n - 1) * a.in2.sn + int64_t(a.in2.h - 1) * a.in2.sh + int64_t(a.in2.w - 1) * a.in2.sw + a.in2.c;
+    if (a.sh != 1 || a.sw != 1) {
+        switch (tile) {
+            case 0: return launch_ws8_t<8, 8, false, true>(a, stream);
+            case 1: return launch_ws8_t<4, 8, false, true>(a, stream);
+            case 2: return launch_ws8_t<2, 8, false, true>(a, stream);
+            case 3: return launch_ws8_t<4, 4, false, true>(a, stream);
+            case 4: return launch_ws8_t<2, 4, false, true>(a, stream);
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (tile) {
         case 0: return launch_ws8_t<8, 8, false>(a, stream);
         case 1: return dual ? launch_ws8_t<4, 8, true>(a, stream) : launch_ws8_t<4, 8, false>(a, stream);
@@ -598,6 +622,11 @@ hipError_t InitKernelsWs8() {
     IE_WS8I(8, 8, false) IE_WS8I(4, 8, false) IE_WS8I(2, 8, false) IE_WS8I(4, 4, false) IE_WS8I(2, 4, false)
     IE_WS8I(4, 8, true) IE_WS8I(2, 8, true) IE_WS8I(4, 4, true) IE_WS8I(2, 4, true)
 #undef IE_WS8I
+#define IE_WS8S(TN, W)                                                                                                                                 \
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_ws_f8_kernel<TN, W, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                 160 * 1024)) != hipSuccess) return e;
+    IE_WS8S(8, 8) IE_WS8S(4, 8) IE_WS8S(2, 8) IE_WS8S(4, 4) IE_WS8S(2, 4)
+#undef IE_WS8S
 #define IE_WS38I(T, NKK)                                                                                                                   \
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_ws_f8_kernel<kWs3Tiles8[T].waves, kWs3Tiles8[T].tmw, kWs3Tiles8[T].pit, NKK>), \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;

@@ -1000,7 +1000,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                         if (t >= 0 && t < kNumIgemmBaseTiles && !(kIgemmTiles[t].bn > 32 && N <= 32)) s.tile = t;
                         // >= 100: the weights-stationary 1x1 kernel's tiles, >= 200: the 3x3's (kernels_ws8.hip); a launcher that declines the
                         // operands hands the step back to the tiled kernel (executor)
-                        if (t >= 100 && t < 105 && n.kh == 1 && n.kw == 1 && n.sh == 1 && n.sw == 1) s.tile = t;
+                        if (t >= 100 && t < 105 && n.kh == 1 && n.kw == 1) s.tile = t;           // (strided 1x1 convs too: the kernel's STR form)
                         if (t >= 200 && t < 204 && is3x3) s.tile = t;
                     }
                     break;
@@ -1310,15 +1310,15 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
         }
     }
 
-    // ---- stem + max pool (fp16 / fp8): the 7x7/s2 stem conv and the 3x3/s2/p1 max pool behind it -> ONE step -------------------------------------
-    // Pattern: step i = the stem conv (algo Stem, ReLU'd, half or e4m3 output), step i + 1 = a max pool 3x3 / stride 2 / pad 1 without a prologue that
+    // ---- stem + max pool: the 7x7/s2 stem conv and the 3x3/s2/p1 max pool behind it -> ONE step -------------------------------------
+    // Pattern: step i = the stem conv (algo Stem, ReLU'd), step i + 1 = a max pool 3x3 / stride 2 / pad 1 without a prologue that
     // reads exactly step i's output, which nothing else reads.  conv_stem_kernel<POOL> (kernels_stem.hip) pools the conv tile in LDS: the tensor
     // between the two ops (the largest of DenseNet / ResNet) is never written.  parts = {conv, pool}; tile 1 = fused, 0 = the two launches.
-    if (precision != Precision::F32 && !env.get("IE_NO_STEM_POOL")) {
+    if (!env.get("IE_NO_STEM_POOL")) {
         for (size_t i = 0; i + 1 < plan.steps.size(); ++i) {
             const Step& c = plan.steps[i];
             const Step& pl = plan.steps[i + 1];
-            if (c.kind != StepKind::Conv || c.algo != ConvAlgo::Stem || !c.relu || c.has_in2 || !c.parts.empty() || !(c.out.f16 || c.out.f8) || c.out.c > 64 || c.out.c % 8) continue;
+            if (c.kind != StepKind::Conv || c.algo != ConvAlgo::Stem || !c.relu || c.has_in2 || !c.parts.empty() || c.out.nchw || c.out.c > 64 || c.out.c % 8) continue;
             if (pl.kind != StepKind::Pool || !pl.pool_max || pl.kh != 3 || pl.kw != 3 || pl.sh != 2 || pl.sw != 2 || pl.pt != 1 || pl.pl != 1 || pl.pb > 1 || pl.pr > 1) continue;
             if (pl.pre_scale_off >= 0 || pl.pre_relu || pl.has_in2 || pl.in_src != int(i)) continue;
             if (pl.in.buf != c.out.buf || pl.in.c_off != c.out.c_off || pl.in.c != c.out.c || pl.in.pitch != c.out.pitch || pl.in.h != c.out.h || pl.in.w != c.out.w) continue;

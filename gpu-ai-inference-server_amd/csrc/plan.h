@@ -56,7 +56,7 @@ enum class ConvAlgo : int {
     X6 = 11,          // fp32 1x1 conv on the bf16 matrix pipe with exactly split operands (kernels_x6.hip; opt-in IE_FP32_SPLIT=1)
     DenseBlock = 12,  // fp16: a chain of dense layers (1x1 K -> 128, 3x3 128 -> 32) in ONE launch, one workgroup per image, the bottleneck tensor
                       // kept in LDS (kernels_block.hip).  Step::parts = the 2n conv steps as the planner emitted them; tile 1 = fused, 0 = the parts
-    StemPool = 14,    // fp16 / fp8: the stem conv AND the 3x3/s2/p1 max pool behind it in one launch (conv_stem_kernel<POOL>, kernels_stem.hip): the conv
+    StemPool = 14,    // the stem conv AND the 3x3/s2/p1 max pool behind it in one launch (conv_stem_kernel<POOL>, kernels_stem.hip): the conv
                       // tile is pooled in LDS, the tensor between the two ops never exists.  Step::parts = {conv, pool}; tile 1 = fused, 0 = the parts
     DualF8 = 13,      // fp8: a bottleneck block's last 1x1 conv AND the projection conv of its shortcut as two GEMMs of one launch (kernels_ws8.hip):
                       // the shortcut tensor never exists.  Step::parts = {projection conv, last conv}; this step's own fields repeat the last

@@ -906,12 +906,14 @@ def test_fp16_dense_block_chain_kernel(tmp_path, batch, image, stem, blocks, ban
     assert e < F16_RTOL and e0 < F16_RTOL and d < F16_RTOL
 
 
+@pytest.mark.parametrize("prec", ["fp16", "fp32"])
 @pytest.mark.parametrize("batch,image,stem", [(1, 32, 64), (3, 50, 32), (2, 62, 64), (5, 224, 64), (2, 230, 16), (9, 112, 48)])
-def test_fp16_stem_and_max_pool_in_one_launch(tmp_path, batch, image, stem):
+def test_stem_and_max_pool_in_one_launch(tmp_path, batch, image, stem, prec):
     """conv_stem_kernel<POOL> (kernels_stem.hip): the 7x7/s2 stem conv and the 3x3/s2/p1 max pool behind it as ONE step (plan algo "stem_pool"), the
-    conv tile pooled in LDS.  Even and odd conv / pooled sizes (ragged 7 x 7 pooled tiles, windows hanging over every image edge), 16 ... 64 stem
-    channels: bit-identical logits to the same plan run as two launches (IE_NO_STEM_POOL=1: the same MFMA sequence, the same halfs, max is exact) and
-    within F16_RTOL of the float64 oracle."""
+    conv tile pooled in LDS -- half and float variants.  Even and odd conv / pooled sizes (ragged 7 x 7 pooled tiles, windows hanging over every
+    image edge; widths that are and are not multiples of four: 16-byte and scalar window gathers), 16 ... 64 stem channels: bit-identical logits to
+    the same plan run as two launches (IE_NO_STEM_POOL=1: the same MFMA sequence, the same rounding, max is exact) and within the mode's bound of
+    the float64 oracle."""
     mb = models.densenet(batch, growth=16, blocks=(2, 2), stem=stem, image=image, classes=24, seed=57)
     path = models.write_repo(str(tmp_path), "stempool", mb)
     x = models.synthetic_input((batch, 3, image, image), stream="stempool")
@@ -927,16 +929,17 @@ def test_fp16_stem_and_max_pool_in_one_launch(tmp_path, batch, image, stem):
             return y, [p_["kernel"] for p_ in B.Profile(m, 1)], B.DescribeModel(path, batch)["plan"]
         finally:
             m.Destroy()
-    y, kern, plan = _run_with_env(_f16_env(IE_AUTOTUNE="0"), go)
-    y0, kern0, plan0 = _run_with_env(_f16_env(IE_AUTOTUNE="0", IE_NO_STEM_POOL="1"), go)
+    y, kern, plan = _run_with_env(dict(IE_PRECISION=prec, IE_AUTOTUNE="0"), go)
+    y0, kern0, plan0 = _run_with_env(dict(IE_PRECISION=prec, IE_AUTOTUNE="0", IE_NO_STEM_POOL="1"), go)
     s0 = plan["steps"][0]
     conv_hw = (image + 6 - 7) // 2 + 1
+    tag = "f16" if prec == "fp16" else "f32"
     assert s0["algo"] == "stem_pool" and s0["tile"] == 1 and s0["out"]["h"] == (conv_hw - 1) // 2 + 1 and plan0["steps"][0]["algo"] == "stem" and plan0["steps"][1]["kind"] == "pool"
-    assert kern[0].startswith("conv_stem_kernel<f16,pool") and kern0[0] == "conv_stem_kernel<f16>" and kern0[1].startswith("pool_kernel") and len(kern) == len(kern0) - 1, (kern[:2], kern0[:3])
+    assert kern[0] == f"conv_stem_kernel<{tag},pool>" and kern0[0] == f"conv_stem_kernel<{tag}>" and kern0[1].startswith("pool_kernel") and len(kern) == len(kern0) - 1, (kern[:2], kern0[:3])
     e = rel_err(y, ref)
-    print(f"stem + pool B={batch} image={image} ({conv_hw} -> {s0['out']['h']}) stem={stem}: rel err {e:.2e}, max |one launch - two launches| {np.abs(y - y0).max():.1e}")
+    print(f"stem + pool {prec} B={batch} image={image} ({conv_hw} -> {s0['out']['h']}) stem={stem}: rel err {e:.2e}, max |one launch - two launches| {np.abs(y - y0).max():.1e}")
     assert np.array_equal(y, y0)
-    assert e < F16_RTOL
+    assert e < (F16_RTOL if prec == "fp16" else RTOL)
 
 
 def test_fp16_densenet121_fixture_and_batch_independence(densenet_repo, tmp_path):
@@ -1628,7 +1631,8 @@ def test_fp8_resnet_mini_every_tile(tmp_path, tile):
 
 @pytest.mark.parametrize("tile", [100, 101, 102, 103, 104, 200, 201, 202, 203])
 def test_fp8_weights_stationary_kernels(tmp_path, tile):
-    """conv1x1_ws_f8_kernel (tiles 100-104, also its DUAL form for the projection shortcut of the first block) and conv3x3_ws_f8_kernel (tiles
+    """conv1x1_ws_f8_kernel (tiles 100-104, also its DUAL form for the projection shortcut of the first block and its STRIDED-input form for the
+    stride-2 projection shortcut of the second stage) and conv3x3_ws_f8_kernel (tiles
     200-203) forced on a bottleneck ResNet whose channel counts are multiples of 32 (every 1x1 / 3x3 stride-1 conv qualifies): against the fp8
     plan emulation (same quantisation points: kernel correctness), the float64 oracle (stated fp8 bound) and the tiled fp8 kernel's answer."""
     from oracle import fp8 as F
@@ -1654,6 +1658,8 @@ def test_fp8_weights_stationary_kernels(tmp_path, tile):
     nws = sum(k.startswith(want) for k in kern)
     assert nws >= (4 if tile < 200 else 2), kern         # (the strided 3x3 of a stage's first block stays on the tiled kernel)
     assert any(k.startswith("conv1x1_ws_f8_kernel<dual") for k in kern), kern          # the first block's projection shortcut: one launch, two GEMMs
+    if tile < 200:       # every 1x1 runs weights-stationary, the STRIDED projection shortcut of stage 2 included: only the four 3x3 convs stay tiled
+        assert sum(k.startswith("conv_igemm_f8_kernel") for k in kern) == 4, kern
     plan, blob = _run_with_env(dict(IE_PRECISION="fp8", **env), lambda: (B.DescribeModel(path, 3)["plan"], B.PlanWeights(path, 3)))
     emu = F.run_plan(plan, blob, {"data": x}, act_scales=info["f8_act_scales"], fp8=True)["logits"]
     e_emu, e_ref, e_t = rel_err(y, emu), rel_err(y, ref), rel_err(y, y0)
