@@ -49,7 +49,9 @@ def _compile(src: str, force: bool) -> str:
     if force or _stale(obj, _deps(src)):
         cmd = [HIPCC, *COMMON, "-c", os.path.join(CSRC, src), "-o", obj]
         if src.endswith(".hip"):
-            cmd[1:1] = ["--offload-arch=" + ARCH]
+            # MFMA accumulators in ordinary VGPRs: for the 256-thread kernels the compiler otherwise parks them in AGPRs (a v_accvgpr_read / _write per
+            # element in every epilogue, and 170 + 64 registers instead of 170: one wave per SIMD fewer); scripts/isa_regs.py tabulates both builds
+            cmd[1:1] = ["--offload-arch=" + ARCH, "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

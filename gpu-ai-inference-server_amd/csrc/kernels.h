@@ -126,6 +126,9 @@ hipError_t LaunchConvDirect(const ConvArgs& a, int tile, hipStream_t stream);
 hipError_t InitKernelsDirect();
 // Stem conv (7x7 / stride 2 / pad 3, Cin = 3, Cout <= 64) straight from the dense NCHW fp32 graph input (kernels_stem.hip);
 // half arithmetic + half output in fp16 mode, fp32 otherwise.
+// Workgroups of `kernel` (block threads, lds dynamic LDS bytes) one CU holds, from the occupancy API (registers included), cached.
+int ResidentPerCu(const void* kernel, int block, size_t lds);
+
 bool ConvStemEligible(const ConvArgs& a);
 hipError_t LaunchConvStem(const ConvArgs& a, hipStream_t stream);
 // The stem AND the 3x3 / stride 2 / pad 1 max pool behind it in one launch: `a` is the stem's argument set with out = the POOLED tensor.

@@ -559,21 +559,26 @@ hipError_t LaunchSplitKReduce(const ConvArgs& a, int splitk, hipStream_t stream)
 
 // Resident workgroups the chip can hold for this kernel (occupancy API x CU count), and the persistent grid derived from
 // it: never more workgroups than tiles; a multiple of 8 so the XCD-aware tile remap keeps lin % 8 == blockIdx.x % 8.
-static int PersistentSlots(const void* kernel, int block, size_t lds) {
+// Workgroups of `kernel` one CU holds (registers, LDS, wave slots: the occupancy API), cached per (kernel, LDS bytes).
+int ResidentPerCu(const void* kernel, int block, size_t lds) {
     static std::mutex mu;
     static std::map<std::pair<const void*, size_t>, int> cache;
-    static int cus = 0;
     std::lock_guard<std::mutex> g(mu);
     auto it = cache.find({kernel, lds});
     if (it != cache.end()) return it->second;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, lds) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
+    return cache[{kernel, lds}] = per_cu;
+}
+
+static int PersistentSlots(const void* kernel, int block, size_t lds) {
+    static int cus = 0;
     if (cus == 0) {
         int dev = 0;
         hipDeviceProp_t prop;
         cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
     }
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, lds) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
-    return cache[{kernel, lds}] = per_cu * cus;
+    return ResidentPerCu(kernel, block, lds) * cus;
 }
 static int PersistentGrid(int num_tiles, int slots, int splitk) {
     const bool off = Knobs().no_persistent;

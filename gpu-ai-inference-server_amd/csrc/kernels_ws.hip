@@ -15,6 +15,10 @@
 
 #include "kernels.h"
 
+#ifndef WS_ABLATE
+#define WS_ABLATE 0       // scripts/probes/ws_probe.cpp builds variants with parts of conv1x1_ws_f16_kernel switched off (timing only, wrong results)
+#endif
+
 namespace ie {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -27,7 +31,10 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 // Register chunks (32 channels x 32 pixels = 2 KiB each) a wave keeps in flight: 4 beside 64 accumulator registers, 6 otherwise.
 constexpr int ws_ring_depth(int tn) { return tn >= 4 ? 4 : 6; }
 
-template <int TN, int WAVES, bool PRE>
+// FAST: half output, no residual -- the epilogue DenseNet's bottleneck and transition convs take.  The accumulators START at the bias (16-byte LDS
+// reads straight into them at the top of a row block: no zeroing, no bias add), the results are rounded to half first and the ReLU is one packed max
+// per two values: ~100 instructions per 32 x 128 outputs where the general epilogue (flags tested at run time, fp32 ReLU, separate zeroing) took ~350.
+template <int TN, int WAVES, bool PRE, bool FAST>
 __global__ __launch_bounds__(64 * WAVES) void conv1x1_ws_f16_kernel(const ConvArgs a) {
     constexpr int NT = 64 * WAVES, BN = 32 * TN, D = ws_ring_depth(TN);
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_ws[];
@@ -57,7 +64,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_ws_f16_kernel(const ConvAr
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(a.in.p, 0, int(a.in_bytes), 0x00020000);
     auto issue = [&](int slot) {
         const int m = rb_l * 32 + r;
-        const unsigned off = (rb_l < nrb && m < M) ? unsigned(m * ipitch + c_l * 32 + hh * 8) * 2u : OOB;
+        const unsigned off = (rb_l < nrb && m < M && WS_ABLATE != 5 && WS_ABLATE != 8) ? unsigned(m * ipitch + c_l * 32 + hh * 8) * 2u : OOB;
         ring[slot][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0);
         ring[slot][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off + 32u, 0, 0);
         if (++c_l == CH) { c_l = 0; rb_l += stride; }
@@ -73,7 +80,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_ws_f16_kernel(const ConvAr
         // U loads in flight per thread: a one-at-a-time loop would pay the L2 round trip BN*K/(8*NT) times in a row
         constexpr int U = 8;
         const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(w), 0, Cout * K * 2, 0x00020000);
-        for (int idx0 = tid; idx0 < BN * k8; idx0 += U * NT) {
+        for (int idx0 = tid; idx0 < (WS_ABLATE == 1 ? 0 : BN * k8); idx0 += U * NT) {
             u32x4 v[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -102,10 +109,17 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_ws_f16_kernel(const ConvAr
     __syncthreads();
 
     f32x16 acc[TN];
+    auto start_at_bias = [&]() {
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(sBias + j * 32 + 8 * g + 4 * hh);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[j][4 * g + q] = bq[q];
+            }
+    };
+    start_at_bias();
 
     // weight fragments are read one (kk, j) step ahead of the MFMA that consumes them (LDS latency behind the previous MFMA)
     auto compute = [&](const u32x4 c0, const u32x4 c1) {
@@ -114,7 +128,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_ws_f16_kernel(const ConvAr
         h8 bfr[2];
         bfr[0] = *reinterpret_cast<const h8*>(Bp);
         h8 av[2] = {__builtin_bit_cast(h8, c0), __builtin_bit_cast(h8, c1)};
-        if constexpr (PRE) {
+        if constexpr (PRE && WS_ABLATE != 2) {
             h8 s[2], t[2];
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -127,7 +141,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_ws_f16_kernel(const ConvAr
                 if (a.pre_relu) av[kk] = __builtin_elementwise_max(av[kk], h8{});
             }
         }
-        __builtin_amdgcn_sched_group_barrier(0x100, PRE ? 5 : 1, 0);      // the reads above go first
+        __builtin_amdgcn_sched_group_barrier(0x100, (PRE && WS_ABLATE != 2) ? 5 : 1, 0);      // the reads above go first
 #pragma unroll
         for (int st = 0; st < 2 * TN; ++st) {
             const int kk = st / TN, j = st % TN;
@@ -136,7 +150,8 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_ws_f16_kernel(const ConvAr
                 bfr[(st + 1) & 1] = *reinterpret_cast<const h8*>(Bp + j1 * 32 * P + k1 * 16);
             }
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bfr[st & 1], av[kk], acc[j], 0, 0, 0);
-            // pin the order "next fragment read, then this step's MFMA" (the scheduler otherwise sinks the read to its use)
+            // pin the order "next fragment read, then this step's MFMA": left alone the scheduler hoists every fragment read of the chunk to its
+            // top (142 registers for the FAST variants instead of 132, 256+ and spills for the general ones)
             if (st + 1 < 2 * TN) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
@@ -151,21 +166,35 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_ws_f16_kernel(const ConvAr
     const int rpitch = int(a.res.sw);
     const __amdgpu_buffer_rsrc_t rs_res =
         __builtin_amdgcn_make_buffer_rsrc(has_res ? a.res.p : a.out.p, 0, has_res ? int((int64_t(M - 1) * rpitch + Cout) * esz) : 0, 0x00020000);
+    const h2 relu_floor = a.relu ? h2{_Float16(0.f), _Float16(0.f)} : h2{-__builtin_inff16(), -__builtin_inff16()};       // FAST: ReLU = packed max with this
     auto epilogue = [&]() {
         const int m = rb_c * 32 + r;
-        const unsigned rowoff = m < M ? unsigned(m * opitch * esz) : OOB;
+        const unsigned rowoff = (m < M && WS_ABLATE != 3 && WS_ABLATE != 8) ? unsigned(m * opitch * esz) : OOB;
+        if constexpr (FAST) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    h2 p[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        p[t] = __builtin_elementwise_max(h2{_Float16(acc[j][8 * gp + 2 * t]), _Float16(acc[j][8 * gp + 2 * t + 1])}, relu_floor);
+                    // quads (g, hh) -> after the half-wave exchange lane (r, hh) holds channels 8*(2gp+hh) .. +7 of pixel r
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, p[0]), __builtin_bit_cast(unsigned, p[2]), false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, p[1]), __builtin_bit_cast(unsigned, p[3]), false, false);
+                    const int n = n0 + j * 32 + 8 * (2 * gp + hh);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rs_out, n < Cout ? rowoff + unsigned(n * 2) : OOB, 0, 0);
+                }
+            }
+            start_at_bias();
+            return;
+        }
         const unsigned rrow = (has_res && m < M) ? unsigned(m * rpitch * esz) : OOB;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             float v[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) v[e] = acc[j][e];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 bq = *reinterpret_cast<const f32x4*>(sBias + j * 32 + 8 * g + 4 * hh);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[4 * g + q] += bq[q];
-            }
             if (has_res) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -184,10 +213,8 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_ws_f16_kernel(const ConvAr
                 }
             }
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
+            for (int e = 0; e < 16; ++e)
                 if (a.relu) v[e] = fmaxf(v[e], 0.f);
-                acc[j][e] = 0.f;
-            }
             if (store_half) {
                 // quads (g, hh) -> after the half-wave exchange lane (r, hh) holds channels 8*(2gp+hh) .. +7 of pixel r
 #pragma unroll
@@ -210,6 +237,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_ws_f16_kernel(const ConvAr
                 }
             }
         }
+        start_at_bias();
     };
 
     // The ring slot is wave-uniform: a scalar jump copies the slot's registers to the operand registers (the load has to
@@ -261,7 +289,7 @@ bool ConvWsEligible(const ConvArgs& a, int tile) {
     return true;
 }
 
-template <int TN, int WAVES, bool PRE>
+template <int TN, int WAVES, bool PRE, bool FAST>
 static hipError_t launch_ws_t(const ConvArgs& a, bool one_per_wave, hipStream_t stream) {
     const int64_t M = int64_t(a.in.n) * a.in.h * a.in.w;
     const int nrb = int((M + 31) / 32);
@@ -274,16 +302,21 @@ static hipError_t launch_ws_t(const ConvArgs& a, bool one_per_wave, hipStream_t 
         cus = prop.multiProcessorCount;
     }
     // resident workgroups: LDS and 2048 threads per CU; then the smallest grid with the same number of row blocks per wave
+    // (LDS and wave slots only: sizing the grid by the true residency -- registers included, ResidentPerCu() -- measured SLOWER: a few workgroups more
+    //  than fit at once cost less than a fifth row block for every wave, e.g. K = 128 at batch 128: 39 us vs 55 us)
     int per_cu = int((size_t(160) * 1024) / lds);
     per_cu = per_cu < 1 ? 1 : (per_cu > 2048 / (64 * WAVES) ? 2048 / (64 * WAVES) : per_cu);
     if (per_cu > 4) per_cu = 4;
+#ifdef WS_PER_CU
+    per_cu = WS_PER_CU;                      // (probe builds)
+#endif
     const int gy = (a.out.c + 32 * TN - 1) / (32 * TN);
     int slots = cus * per_cu / gy;           // the resident workgroups are shared by the gy N-tiles
     if (slots < 8) slots = 8;
     const int iters = one_per_wave ? 1 : (nrb + slots * WAVES - 1) / (slots * WAVES);
     int gx = (nrb + iters * WAVES - 1) / (iters * WAVES);
     gx = (gx + 7) & ~7;                      // same x -> same XCD for the N-tiles of one row range
-    conv1x1_ws_f16_kernel<TN, WAVES, PRE><<<dim3(gx, gy), dim3(64 * WAVES), lds, stream>>>(a);
+    conv1x1_ws_f16_kernel<TN, WAVES, PRE, FAST><<<dim3(gx, gy), dim3(64 * WAVES), lds, stream>>>(a);
     return hipGetLastError();
 }
 
@@ -291,8 +324,11 @@ hipError_t LaunchConvWs1x1F16(const ConvArgs& a_in, int tile, hipStream_t stream
     if (!ConvWsEligible(a_in, tile)) return hipErrorInvalidValue;
     ConvArgs a = a_in;
     a.in_bytes = 2 * (int64_t(a.in.n - 1) * a.in.sn + int64_t(a.in.h - 1) * a.in.sh + int64_t(a.in.w - 1) * a.in.sw + int64_t(a.in.c - 1) + 1);
-#define IE_WS(T, TN, W) \
-    case T: return a.pre_scale ? launch_ws_t<TN, W, true>(a, tile >= 6, stream) : launch_ws_t<TN, W, false>(a, tile >= 6, stream);
+    const bool fast = a.out.f16 && a.res.p == nullptr;
+#define IE_WS(T, TN, W)                                                                                                                                  \
+    case T:                                                                                                                                              \
+        return a.pre_scale ? (fast ? launch_ws_t<TN, W, true, true>(a, tile >= 6, stream) : launch_ws_t<TN, W, true, false>(a, tile >= 6, stream))       \
+                           : (fast ? launch_ws_t<TN, W, false, true>(a, tile >= 6, stream) : launch_ws_t<TN, W, false, false>(a, tile >= 6, stream));
     switch (tile % 6) {
         IE_WS(0, 4, 8) IE_WS(1, 4, 4) IE_WS(2, 2, 8) IE_WS(3, 2, 4) IE_WS(4, 1, 8) IE_WS(5, 1, 4)
         default: return hipErrorInvalidValue;
@@ -302,11 +338,11 @@ hipError_t LaunchConvWs1x1F16(const ConvArgs& a_in, int tile, hipStream_t stream
 
 hipError_t InitKernelsWs() {
     hipError_t e;
-#define IE_WSI(TN, W)                                                                                                                       \
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_ws_f16_kernel<TN, W, true>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                 160 * 1024)) != hipSuccess) return e;                                                                       \
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_ws_f16_kernel<TN, W, false>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                 160 * 1024)) != hipSuccess) return e;
+#define IE_WSI(TN, W)                                                                                                                                                                      \
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_ws_f16_kernel<TN, W, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;   \
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_ws_f16_kernel<TN, W, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;  \
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_ws_f16_kernel<TN, W, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;  \
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_ws_f16_kernel<TN, W, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     IE_WSI(4, 8) IE_WSI(4, 4) IE_WSI(2, 8) IE_WSI(2, 4) IE_WSI(1, 8) IE_WSI(1, 4)
 #undef IE_WSI
     return hipSuccess;

@@ -10,6 +10,14 @@
 #include <cstring>
 #include <vector>
 
+namespace ie {      // (lives in kernels.hip in the library)
+int ResidentPerCu(const void* kernel, int block, size_t lds) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, block, lds) != hipSuccess || n < 1) { (void)hipGetLastError(); n = 1; }
+    return n;
+}
+}  // namespace ie
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s failed: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 static ie::TensorArg nhwc8(void* p, int n, int h, int w, int c) {
