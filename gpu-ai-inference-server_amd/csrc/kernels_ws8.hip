@@ -142,15 +142,17 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_ws_f8_kernel(const ConvArg
         };
         stage_w(a.w8, K1, P1, sB1);
         if constexpr (DUAL) stage_w(a.w8b, K2, P2, sB2);
+        // the output's 1 / scale is folded into the per-channel constants here, once per workgroup: the epilogue is one fma per product, one per
+        // shortcut element and ONE v_med3_f32 for ReLU + e4m3 range clamp (scaling by a positive number commutes with both)
         for (int idx = tid; idx < BN; idx += NT) {
             const bool ok = n0 + idx < Cout;
-            sE1[idx] = ok ? a.escale[n0 + idx] : 0.f;
+            sE1[idx] = ok ? a.escale[n0 + idx] * a.out_qscale : 0.f;
             float b = (ok && a.bias) ? a.bias[n0 + idx] : 0.f;
             if constexpr (DUAL) {
-                sE2[idx] = ok ? a.escale_b[n0 + idx] : 0.f;
+                sE2[idx] = ok ? a.escale_b[n0 + idx] * a.out_qscale : 0.f;
                 if (ok && a.bias_b) b += a.bias_b[n0 + idx];
             }
-            sBi[idx] = b;
+            sBi[idx] = b * a.out_qscale;
         }
     }
     __syncthreads();
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_ws_f8_kernel(const ConvArg
     const bool has_res = a.res.p != nullptr;
     const int rpitch = int(a.res.sw);
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(has_res ? a.res.p : a.out.p, 0, has_res ? int(int64_t(M - 1) * rpitch + Cout) : 0, 0x00020000);
-    const float qs = a.out_qscale, rsc = a.res_scale;
+    const float rsq = a.res_scale * a.out_qscale, lo = a.relu ? 0.f : -kE4m3Max8;
     auto epilogue = [&]() {
         const int m = rb_c * 32 + r;
         const unsigned rowoff = m < M ? unsigned(m * opitch) : kOOB8;
@@ -225,13 +227,13 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_ws_f8_kernel(const ConvArg
                     float rv[4];
                     unpack4_e4m3_ws(rq[gq], rv);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] += rv[q] * rsc;
+                    for (int q = 0; q < 4; ++q) v[q] += rv[q] * rsq;
                 }
-                if (a.relu) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
-                }
-                d[gq] = pack4_e4m3_ws(v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs);
+                for (int q = 0; q < 4; ++q) v[q] = __builtin_amdgcn_fmed3f(v[q], lo, kE4m3Max8);
+                int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+                pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], pk, true);
+                d[gq] = unsigned(pk);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     acc[j][4 * gq + q] = 0.f;
