@@ -22,7 +22,7 @@ LIB = os.path.join(PKG, "lib", "libinference_engine.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-SOURCES = ["env.cpp", "onnx_reader.cpp", "plan.cpp", "repository.cpp", "config.cpp", "executor.cpp", "bridge.cpp", "kernels.hip", "kernels_f16.hip", "kernels_ws.hip", "kernels_ws32.hip", "kernels_stem.hip", "kernels_direct.hip", "kernels_f8.hip", "kernels_fused.hip", "kernels_wino.hip", "kernels_x6.hip", "kernels_block.hip", "kernels_ws8.hip"]
+SOURCES = ["env.cpp", "onnx_reader.cpp", "plan.cpp", "repository.cpp", "config.cpp", "executor.cpp", "bridge.cpp", "bridge_load.cpp", "bridge_run.cpp", "kernels.hip", "kernels_f16.hip", "kernels_ws.hip", "kernels_ws32.hip", "kernels_stem.hip", "kernels_direct.hip", "kernels_f8.hip", "kernels_fused.hip", "kernels_wino.hip", "kernels_x6.hip", "kernels_block.hip", "kernels_ws8.hip"]
 COMMON = ["-std=c++17", "-O3", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter", "-Wno-unused-result",
           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 

@@ -10,38 +10,7 @@
 //   * ModelInfer never writes more dims than the caller's array holds and zero-fills the unused tail of an
 //     output buffer (the reference overflows / leaves it uninitialised, inference_bridge.cpp:794-812)
 //   * no CPU execution provider: without a HIP device Load fails loudly
-#include <atomic>
-#include <cctype>
-#include <dlfcn.h>
-#include <chrono>
-#include <condition_variable>
-#include <deque>
-#include <functional>
-#include <shared_mutex>
-#include <cstdlib>
-#include <cstring>
-#include <filesystem>
-#include <fstream>
-#include <iostream>
-#include <memory>
-#include <mutex>
-#include <sstream>
-#include <string>
-#include <thread>
-#include <unordered_map>
-#include <vector>
-
-#include "../../include/inference_bridge.h"
-#include "../../include/inference_engine_ext.h"
-#include <rccl/rccl.h>
-
-#include "config.h"
-#include "env.h"
-#include "executor.h"
-#include "kernels.h"
-#include "onnx_reader.h"
-#include "plan.h"
-#include "repository.h"
+#include "bridge_internal.h"
 
 static_assert(sizeof(Shape) == 16, "Shape layout");
 static_assert(sizeof(TensorData) == 48 && offsetof(TensorData, data) == 32 && offsetof(TensorData, data_size) == 40, "TensorData layout");
@@ -50,483 +19,7 @@ static_assert(sizeof(ModelMetadata) == 72 && offsetof(ModelMetadata, load_time_n
 static_assert(sizeof(ModelStats) == 32, "ModelStats layout");
 static_assert(sizeof(CudaMemoryInfo) == 24, "CudaMemoryInfo layout");
 
-namespace {
-
-// Optional ROCTX ranges: one range per ModelInfer call, named after the model, when IE_ROCTX=1 and the ROCm
-// marker library is present (`rocprofv3 --marker-trace` then shows requests next to the kernels).  Loaded lazily with dlopen so
-// the engine keeps libamdhip64 as its only link-time dependency.
-struct Roctx {
-    int (*push)(const char*) = nullptr;
-    int (*pop)() = nullptr;
-    Roctx() {
-        const ie::Env env = ie::Env::Read();
-        const char* e = env.get("IE_ROCTX");
-        if (!e || e[0] != '1') return;
-        for (const char* name : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
-            if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
-                push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
-                pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
-                if (push && pop) return;
-                push = nullptr; pop = nullptr;
-            }
-        }
-    }
-};
-const Roctx& roctx() { static Roctx r; return r; }
-struct RoctxRange {
-    bool on;
-    explicit RoctxRange(const std::string& name) : on(roctx().push != nullptr) { if (on) roctx().push(name.c_str()); }
-    ~RoctxRange() { if (on) roctx().pop(); }
-};
-
-
-char* dup_cstr(const std::string& s) {
-    char* p = static_cast<char*>(std::malloc(s.size() + 1));
-    if (p) std::memcpy(p, s.c_str(), s.size() + 1);
-    return p;
-}
-void set_error(ErrorMessage* error, const std::string& msg) {
-    if (error) *error = dup_cstr(msg);
-}
-
-// A model's execution lanes (ie::DeviceModel objects) are used by one host thread at a time.  Requests that run on ONE lane take any
-// free one (config.json "instance_count" lanes on the primary device + the shard replicas); a sharded request takes the first
-// `n` lanes together and waits for them to drain first.
-struct LanePool {
-    std::mutex mu;
-    std::condition_variable cv;
-    std::vector<char> busy;
-    int exclusive_waiters = 0;
-    int in_flight = 0, max_in_flight = 0;
-    void Reset(size_t n) { std::lock_guard<std::mutex> g(mu); busy.assign(n, 0); exclusive_waiters = 0; in_flight = 0; }
-    // prefer the highest-numbered free lane: extra lanes first, so lane 0 (EnginePrepare / EngineRunPrepared) stays free longest
-    int AcquireAny() {
-        std::unique_lock<std::mutex> lk(mu);
-        int k = -1;
-        cv.wait(lk, [&] {
-            if (exclusive_waiters > 0 || busy.empty()) return busy.empty();
-            for (int i = int(busy.size()) - 1; i >= 0; --i) if (!busy[size_t(i)]) { k = i; return true; }
-            return false;
-        });
-        if (k < 0) return -1;
-        busy[size_t(k)] = 1;
-        max_in_flight = std::max(max_in_flight, ++in_flight);
-        return k;
-    }
-    void AcquireOne(int k) {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return size_t(k) < busy.size() && !busy[size_t(k)]; });
-        busy[size_t(k)] = 1;
-        max_in_flight = std::max(max_in_flight, ++in_flight);
-    }
-    void AcquireRange(int n) {
-        std::unique_lock<std::mutex> lk(mu);
-        ++exclusive_waiters;
-        cv.wait(lk, [&] { for (int i = 0; i < n; ++i) if (busy[size_t(i)]) return false; return true; });
-        --exclusive_waiters;
-        for (int i = 0; i < n; ++i) busy[size_t(i)] = 1;
-        max_in_flight = std::max(max_in_flight, ++in_flight);
-    }
-    void Release(int first, int n) {
-        { std::lock_guard<std::mutex> g(mu); for (int i = first; i < first + n; ++i) busy[size_t(i)] = 0; --in_flight; }
-        cv.notify_all();
-    }
-};
-
-// Persistent helper threads, one per shard replica: a sharded ModelInfer hands slice k to thread k-1 and runs slice 0 itself.
-// (Round 1 spawned and joined std::threads per call; at 4 images per GPU that churn was a first-order cost.)
-class WorkerPool {
-public:
-    ~WorkerPool() { Stop(); }
-    void Start(int n) {
-        Stop();
-        for (int i = 0; i < n; ++i) {
-            ws_.push_back(std::make_unique<W>());
-            W* w = ws_.back().get();
-            w->th = std::thread([this, w] {
-                for (;;) {
-                    std::function<void()> job;
-                    {
-                        std::unique_lock<std::mutex> lk(w->mu);
-                        w->cv.wait(lk, [&] { return w->stop || w->has; });
-                        if (w->stop) return;
-                        job = std::move(w->job);
-                        w->has = false;
-                    }
-                    job();
-                    { std::lock_guard<std::mutex> g(dmu_); --pending_; }
-                    dcv_.notify_all();
-                }
-            });
-        }
-    }
-    void Stop() {
-        for (auto& w : ws_) { { std::lock_guard<std::mutex> g(w->mu); w->stop = true; } w->cv.notify_all(); }
-        for (auto& w : ws_) if (w->th.joinable()) w->th.join();
-        ws_.clear();
-    }
-    size_t size() const { return ws_.size(); }
-    void Submit(size_t k, std::function<void()> fn) {
-        { std::lock_guard<std::mutex> g(dmu_); ++pending_; }
-        W* w = ws_.at(k).get();
-        { std::lock_guard<std::mutex> g(w->mu); w->job = std::move(fn); w->has = true; }
-        w->cv.notify_one();
-    }
-    void Wait() { std::unique_lock<std::mutex> lk(dmu_); dcv_.wait(lk, [&] { return pending_ == 0; }); }
-private:
-    struct W { std::thread th; std::mutex mu; std::condition_variable cv; std::function<void()> job; bool has = false, stop = false; };
-    std::vector<std::unique_ptr<W>> ws_;
-    std::mutex dmu_;
-    std::condition_variable dcv_;
-    int pending_ = 0;
-};
-
-uint64_t fnv1a64(const void* data, size_t n) {
-    const unsigned char* p = static_cast<const unsigned char*>(data);
-    uint64_t h = 1469598103934665603ull;
-    for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
-    return h;
-}
-
-struct ModelObj {
-    std::string path;
-    ModelType type = MODEL_UNKNOWN;
-    DeviceType device = DEVICE_GPU;
-    int device_id = 0;
-    std::string name, version;
-    std::vector<std::string> input_names, output_names;   // config names until Load replaces them with the graph's
-
-    std::shared_mutex life;        // Load / Unload exclusive; everything that touches the lanes holds it shared
-    std::atomic<bool> loaded{false};
-    std::mutex err_mu;
-    std::string last_error;
-    void SetError(const std::string& m) { std::lock_guard<std::mutex> g(err_mu); last_error = m; }
-    std::string GetError() { std::lock_guard<std::mutex> g(err_mu); return last_error; }
-    std::shared_ptr<const ie::OnnxModel> onnx;
-    ie::ModelInfo info;
-    ie::EngineConfig cfg;          // config.json, parsed once at load
-    // Execution lanes.  lanes[0] is the primary.  lanes[1 .. num_shards) are the shard replicas of the in-process batch sharding
-    // (single process, all GPUs of the node; IE_GPUS=<n> / config.json "gpus": n -> devices device_id .. device_id+n-1, or
-    // IE_SHARD_DEVICES=<id,id,...>, ids may repeat, which is how the single-GPU tests exercise the logic).  lanes[num_shards ..) are
-    // extra lanes on the primary device (config.json / ModelConfig "instance_count"): concurrent requests run side by side.
-    // A replica on another device owns its weights and receives the packed blob by ONE ncclBroadcast at load; lanes on a device that
-    // already holds the blob share it.
-    std::vector<std::unique_ptr<ie::DeviceModel>> lanes;
-    int num_shards = 1;
-    LanePool pool;
-    WorkerPool workers;
-    struct RcclInfo { bool used = false; int ranks = 0; size_t bytes = 0; double init_ms = 0, bcast_ms = 0; int owners = 1; } rccl;
-    float u8_scale = 1.0f / 255.0f, u8_bias = 0.0f;
-    int64_t load_time_ns = 0;
-    std::atomic<int64_t> inference_count{0}, total_ns{0}, last_ns{0};
-    std::atomic<size_t> memory_usage_bytes{0};
-    // device-side accounting for the observability string (ModelGetMetadata.description): HIP-event time of the forwards and the
-    // planner's algorithmic FLOPs / bytes of what ran
-    std::mutex acct_mu;
-    double acct_ms = 0, acct_flops = 0, acct_bytes = 0;
-    int64_t acct_forwards = 0, acct_images = 0;
-
-    // ---- dynamic request batcher: honours the reference's inert max_batch_size / dynamic_batching fields
-    // (model.h:63,70-71).  Concurrent ModelInfer calls (one per gin goroutine) are coalesced into ONE device batch and the
-    // results are scattered back per caller.  Enabled by IE_DYNAMIC_BATCH=<max rows> or config.json
-    // {"dynamic_batching": true, "max_batch_size": N}; only for graphs whose inputs/outputs have a symbolic batch axis.
-    struct Pending {
-        std::vector<const void*> in_ptr;
-        std::vector<size_t> in_bytes;
-        std::vector<char> in_u8;          // 1 = UINT8 payload for a FLOAT32 graph input (converted on the device)
-        std::vector<std::vector<int64_t>> shapes;
-        TensorData* outputs = nullptr;
-        int num_outputs = 0;
-        int64_t rows = 0;
-        bool done = false, ok = false;
-        std::string err;
-    };
-    int cfg_max_batch = 0;        // from ModelCreate's ModelConfig {dynamic_batching, max_batch_size}
-    int cfg_instances = 0;        // from ModelCreate's ModelConfig.instance_count
-    int max_batch = 0;            // 0/1 = batching off
-    int batch_window_us = 200;
-    bool batchable = false;       // set at Load: symbolic batch axis on every graph input and output
-    std::mutex bmu;
-    std::condition_variable bcv;
-    std::deque<Pending*> queue;
-    bool leader_active = false;
-    std::atomic<int64_t> device_batches{0}, coalesced_requests{0}, shard_calls{0};
-
-    bool Load();      // model.cpp:503-548 + 825-871
-    void Unload();    // model.cpp:618-648
-    void Execute(std::vector<Pending*>& batch);   // runs one device batch for these callers
-    void RunBatched(Pending& req);                // leader/follower coalescing
-    void BroadcastWeights();                      // RCCL: primary's packed blob -> every other weight owner
-    void Account(ie::DeviceModel& d, const ie::PlanInstance& pi);
-    using Segs = std::pair<std::vector<std::vector<ie::DeviceModel::InSeg>>, std::vector<std::vector<ie::DeviceModel::OutSeg>>>;
-    std::vector<ie::IoDesc> RunOnLanes(const std::vector<std::vector<int64_t>>& shapes, int64_t rows, bool allow_shard, const Segs& segs, bool* sharded);
-};
-
-#define NCCL_OK(call)                                                                                             \
-    do {                                                                                                          \
-        ncclResult_t r_ = (call);                                                                                 \
-        if (r_ != ncclSuccess) throw std::runtime_error(std::string("RCCL error in " #call ": ") + ncclGetErrorString(r_)); \
-    } while (0)
-
-// One communicator per distinct device (ncclCommInitAll, single process), one in-place ncclBroadcast of the packed fp32 blob from
-// the primary to every other device's owner inside a group call, then each receiver rebuilds its derived mirrors.  This is the
-// only collective of the whole path; nothing is exchanged per inference.  The reference has no counterpart: it
-// hard-codes device 0 (inference_bridge.cpp:346-347).
-void ModelObj::BroadcastWeights() {
-    std::vector<ie::DeviceModel*> owners;          // lanes that own a weight allocation of their own, primary first
-    for (auto& l : lanes) {
-        bool first = true;
-        for (auto* o : owners) if (o->shared_weights() == l->shared_weights()) first = false;
-        if (first) owners.push_back(l.get());
-    }
-    rccl.owners = int(owners.size());
-    if (owners.size() < 2) return;
-    std::vector<int> devs;                         // distinct devices, the primary's first = rank 0 = root
-    std::vector<ie::DeviceModel*> rank_owner;
-    for (auto* o : owners)
-        if (std::find(devs.begin(), devs.end(), o->device()) == devs.end()) { devs.push_back(o->device()); rank_owner.push_back(o); }
-    const size_t count = owners[0]->weight_bytes() / sizeof(float);
-    std::vector<ncclComm_t> comms(devs.size(), nullptr);
-    auto t0 = std::chrono::steady_clock::now();
-    NCCL_OK(ncclCommInitAll(comms.data(), int(devs.size()), devs.data()));
-    auto t1 = std::chrono::steady_clock::now();
-    try {
-        if (devs.size() > 1) {
-            NCCL_OK(ncclGroupStart());
-            for (size_t r = 0; r < devs.size(); ++r) {
-                if (hipSetDevice(devs[r]) != hipSuccess) throw std::runtime_error("hipSetDevice failed during the weight broadcast");
-                NCCL_OK(ncclBroadcast(rank_owner[r]->weights(), rank_owner[r]->weights(), count, ncclFloat, 0, comms[r], rank_owner[r]->stream()));
-            }
-            NCCL_OK(ncclGroupEnd());
-            for (auto* o : rank_owner) o->Synchronize();
-        }
-        // further owners on a device that already holds the blob (IE_SHARD_PRIVATE_WEIGHTS=1, how the one-GPU box moves real bytes
-        // through RCCL): with one rank an out-of-place broadcast copies send -> recv; with more ranks a device-to-device copy does
-        for (auto* o : owners) {
-            if (std::find(rank_owner.begin(), rank_owner.end(), o) != rank_owner.end()) continue;
-            const size_t r = size_t(std::find(devs.begin(), devs.end(), o->device()) - devs.begin());
-            if (hipSetDevice(devs[r]) != hipSuccess) throw std::runtime_error("hipSetDevice failed during the weight broadcast");
-            if (devs.size() == 1) NCCL_OK(ncclBroadcast(rank_owner[r]->weights(), o->weights(), count, ncclFloat, 0, comms[r], o->stream()));
-            else if (hipMemcpyAsync(o->weights(), rank_owner[r]->weights(), count * sizeof(float), hipMemcpyDeviceToDevice, o->stream()) != hipSuccess)
-                throw std::runtime_error("device-to-device weight copy failed");
-            o->Synchronize();
-        }
-    } catch (...) {
-        for (auto c : comms) if (c) (void)ncclCommDestroy(c);
-        throw;
-    }
-    auto t2 = std::chrono::steady_clock::now();
-    for (auto c : comms) if (c) (void)ncclCommDestroy(c);
-    // receivers rebuild their derived mirrors; in fp8 mode they adopt the primary's calibrated activation scales (same weights, same
-    // hardware: re-running the calibration pass on every receiver would be 8x redundant work at load)
-    const std::vector<float> scales = owners[0]->f8_act_scales();
-    for (size_t i = 1; i < owners.size(); ++i) owners[i]->WeightsArrived(scales.empty() ? nullptr : &scales);
-    (void)hipSetDevice(device_id);
-    rccl.used = true;
-    rccl.ranks = int(devs.size());
-    rccl.bytes = count * sizeof(float);
-    rccl.init_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
-    rccl.bcast_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
-}
-
-bool ModelObj::Load() {
-    std::unique_lock<std::shared_mutex> g(life);
-    auto t0 = std::chrono::steady_clock::now();
-    std::error_code ec;
-    if (!std::filesystem::exists(path, ec)) {
-        SetError("Model file not found: " + path);
-        return false;
-    }
-    bool ok = false;
-    switch (type) {
-        case MODEL_TENSORFLOW: SetError("TensorFlow model loading not implemented"); break;
-        case MODEL_TENSORRT: SetError("TensorRT model loading not implemented"); break;
-        case MODEL_PYTORCH: SetError("PyTorch model loading not implemented"); break;
-        case MODEL_CUSTOM: SetError("Custom model loading not implemented"); break;
-        case MODEL_ONNX: {
-            try {
-                const ie::Env env = ie::Env::Read();       // this load's switches, read once
-                const std::string file = path + "/model.onnx";
-                if (!std::filesystem::exists(file, ec)) {
-                    SetError("ONNX model file not found: " + file);
-                    break;
-                }
-                if (device != DEVICE_GPU) {
-                    SetError("DEVICE_CPU execution is not provided by the MI355X engine (a HIP device is required)");
-                    break;
-                }
-                auto parsed = std::make_shared<ie::OnnxModel>(ie::LoadOnnxFile(file));
-                ie::ModelInfo inf = ie::DescribeModel(*parsed);
-                ie::EngineConfig conf = ie::LoadEngineConfig(path);       // read ONCE; a malformed file is a load error
-                // Precision: IE_PRECISION=fp16|fp32, else config.json {"precision": "fp16"}; default fp32 (the reference's
-                // ONNX Runtime session computes in the model's own fp32).
-                ie::Precision prec = ie::Precision::F32;
-                {
-                    std::string want = conf.precision;
-                    if (const char* e = env.get("IE_PRECISION")) want = e;
-                    for (auto& ch : want) ch = char(std::tolower(static_cast<unsigned char>(ch)));
-                    if (want == "fp16" || want == "f16" || want == "half" || want == "float16") prec = ie::Precision::F16;
-                    else if (want == "fp8" || want == "f8" || want == "e4m3" || want == "float8") prec = ie::Precision::F8;
-                    else if (!want.empty() && want != "fp32" && want != "f32" && want != "float32" && want != "float") {
-                        SetError("ONNX model loading error: unsupported precision '" + want + "' (fp32, fp16 or fp8)");
-                        break;
-                    }
-                }
-                // UINT8 ingest transform x * scale + bias: config.json "uint8_scale" / "uint8_bias" (default 1/255, 0: the reference
-                // client's /255 convention, client/test_client.py:189)
-                u8_scale = conf.uint8_scale;
-                u8_bias = conf.uint8_bias;
-                ie::DeviceModelOptions opt;
-                opt.precision = prec;
-                opt.fp32_split = conf.fp32_split;
-                opt.tune_cache_path = path + "/.ie_tune." + (prec == ie::Precision::F16 ? "fp16" : (prec == ie::Precision::F8 ? "fp8" : "fp32")) + ".txt";
-                auto primary = std::make_unique<ie::DeviceModel>(parsed, device_id, opt);
-                primary->SetU8Transform(u8_scale, u8_bias);
-                // Plan + tune at load, off the request path (like Ort::Session's constructor, which also rejects unsupported graphs
-                // here): the config's declared shape (symbolic dims -> 1) and every batch size of "tune_batches" / IE_TUNE_BATCHES.
-                std::vector<std::vector<int64_t>> shapes;
-                for (size_t i = 0; i < inf.inputs.size(); ++i) {
-                    std::vector<int64_t> s = inf.inputs[i].dims;
-                    int64_t cfg_batch = 1;
-                    for (const auto& ic : conf.inputs)
-                        if (ic.name == inf.inputs[i].name && ic.shape.size() == s.size() && !ic.shape.empty() && ic.shape[0] > 0) cfg_batch = ic.shape[0];
-                    for (size_t k = 0; k < s.size(); ++k) if (s[k] <= 0) s[k] = (k == 0 ? cfg_batch : 1);
-                    shapes.push_back(s);
-                }
-                primary->Prepare(shapes, true);
-                bool symbolic_batch = !inf.inputs.empty();
-                for (auto& vi : inf.inputs) if (vi.dims.empty() || vi.dims[0] > 0) symbolic_batch = false;
-                for (auto& vi : inf.outputs) if (vi.dims.empty() || vi.dims[0] > 0) symbolic_batch = false;
-                {
-                    std::vector<int64_t> tb = conf.tune_batches;
-                    if (const char* e = env.get("IE_TUNE_BATCHES")) {
-                        tb.clear();
-                        std::stringstream ss(e);
-                        std::string tok;
-                        while (std::getline(ss, tok, ',')) if (!tok.empty()) tb.push_back(std::atoll(tok.c_str()));
-                    }
-                    for (int64_t b : tb) {
-                        if (!symbolic_batch || b <= 0 || b > 65536) continue;
-                        std::vector<std::vector<int64_t>> sh = shapes;
-                        for (auto& s : sh) s[0] = b;
-                        primary->Prepare(sh, true);
-                    }
-                }
-                // ---- shard replicas and extra lanes ----
-                std::vector<int> shard_ids;                       // devices of lanes[1 .. num_shards)
-                if (const char* e = env.get("IE_SHARD_DEVICES")) {
-                    std::stringstream ss(e);
-                    std::string tok;
-                    while (std::getline(ss, tok, ',')) if (!tok.empty()) shard_ids.push_back(std::atoi(tok.c_str()));
-                    if (!shard_ids.empty()) shard_ids.erase(shard_ids.begin());           // the first id is the primary's slice
-                } else {
-                    int n = conf.gpus > 0 ? conf.gpus : 1;
-                    if (const char* e = env.get("IE_GPUS")) n = std::atoi(e);
-                    const int have = ie::HipDeviceCount();
-                    for (int k = 1; k < n && device_id + k < have; ++k) shard_ids.push_back(device_id + k);
-                }
-                if (!symbolic_batch) shard_ids.clear();           // a fixed-batch graph cannot be sliced
-                int instances = conf.instance_count > 0 ? conf.instance_count : (cfg_instances > 0 ? cfg_instances : 1);
-                if (const char* e = env.get("IE_INSTANCES")) instances = std::atoi(e);
-                instances = std::max(1, std::min(instances, 16));
-                const bool private_weights = [&] { const char* e = env.get("IE_SHARD_PRIVATE_WEIGHTS"); return e && e[0] == '1'; }();
-                std::vector<std::unique_ptr<ie::DeviceModel>> built;
-                built.push_back(std::move(primary));
-                struct Spec { int dev; bool shard; };
-                std::vector<Spec> specs;
-                for (int id : shard_ids) specs.push_back({id, true});
-                for (int k = 1; k < instances; ++k) specs.push_back({device_id, false});
-                // constructors run here (they decide who shares whose weights); planning, allocation and graph capture of the
-                // replicas then run in parallel on the shard worker threads
-                for (const Spec& sp : specs) {
-                    ie::DeviceModelOptions o = opt;
-                    o.tune_cache_path.clear();
-                    ie::DeviceModel* holder = nullptr;
-                    if (!(sp.shard && private_weights))
-                        for (auto& l : built) if (l->device() == sp.dev) { holder = l.get(); break; }
-                    if (holder) o.share = holder->shared_weights();
-                    else o.upload_weights = false;                                    // filled by the RCCL broadcast below
-                    auto r = std::make_unique<ie::DeviceModel>(parsed, sp.dev, o);
-                    r->SetU8Transform(u8_scale, u8_bias);
-                    if (!holder) {                                                    // same hardware: adopt the primary's kernel choices
-                        auto& src = *built[0]->shared_weights();
-                        auto& dst = *r->shared_weights();
-                        std::lock_guard<std::mutex> g1(src.tune_mu);
-                        dst.tune_cache = src.tune_cache;
-                    }
-                    built.push_back(std::move(r));
-                }
-                workers.Start(int(shard_ids.size()));
-                if (built.size() > 1) {
-                    std::vector<std::string> errs(built.size());
-                    WorkerPool builders;
-                    builders.Start(int(built.size()) - 1);
-                    for (size_t k = 1; k < built.size(); ++k)
-                        builders.Submit(k - 1, [&, k] {
-                            try { built[k]->Prepare(shapes, false); } catch (const std::exception& e) { errs[k] = e.what(); }
-                        });
-                    builders.Wait();
-                    builders.Stop();
-                    for (auto& e : errs) if (!e.empty()) throw std::runtime_error(e);
-                }
-                lanes = std::move(built);
-                num_shards = int(shard_ids.size()) + 1;
-                rccl = RcclInfo();
-                BroadcastWeights();
-                pool.Reset(lanes.size());
-                input_names.clear();
-                output_names.clear();
-                for (auto& vi : inf.inputs) input_names.push_back(vi.name);
-                for (auto& vi : inf.outputs) output_names.push_back(vi.name);
-                memory_usage_bytes = inf.memory_usage_bytes;   // reference's estimate formula, model.cpp:979-1035
-                batchable = symbolic_batch;
-                {   // batching knobs: environment first, then config.json, then ModelCreate's ModelConfig
-                    max_batch = cfg_max_batch;
-                    if (conf.dynamic_batching && conf.max_batch_size > 1) max_batch = conf.max_batch_size;
-                    if (const char* e = env.get("IE_DYNAMIC_BATCH")) max_batch = std::atoi(e);
-                    if (conf.batch_window_us >= 0) batch_window_us = conf.batch_window_us;
-                    if (const char* e = env.get("IE_BATCH_WINDOW_US")) batch_window_us = std::max(0, std::atoi(e));
-                    if (max_batch > 4096) max_batch = 4096;
-                }
-                onnx = parsed;
-                info = std::move(inf);
-                cfg = std::move(conf);
-                ok = true;
-            } catch (const std::exception& e) {
-                workers.Stop();
-                lanes.clear();
-                SetError(std::string("ONNX model loading error: ") + e.what());
-            }
-            break;
-        }
-        default: SetError("Unsupported model type"); return false;
-    }
-    load_time_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
-    loaded = ok;
-    return ok;
-}
-
-void ModelObj::Unload() {
-    std::unique_lock<std::shared_mutex> g(life);      // waits for every in-flight ModelInfer (they hold it shared)
-    workers.Stop();
-    lanes.clear();
-    pool.Reset(0);
-    onnx.reset();
-    loaded = false;
-}
-
-}  // namespace
-
-struct Model_t {
-    std::shared_ptr<ModelObj> model;
-};
-
-struct InferenceManager_t {
-    std::string repo_path;
-    std::unique_ptr<ie::Repository> repo;
-    std::mutex mu;
-    std::unordered_map<std::string, std::shared_ptr<ModelObj>> models;   // keyed by name only (bridge:320)
-};
+using namespace ie_bridge;
 
 extern "C" {
 
@@ -776,285 +269,6 @@ bool ModelInfer(ModelHandle handle, const TensorData* inputs, int num_inputs, Te
 }
 
 }  // extern "C"
-
-namespace {
-
-// outputs by index, in graph-output order (bridge:787-813); never writes past the caller's dims array
-void write_out_dims(TensorData* outputs, int num_outputs, const std::vector<ie::IoDesc>& odesc, int64_t rows) {
-    for (int i = 0; i < num_outputs && size_t(i) < odesc.size(); ++i) {
-        std::vector<int64_t> dims = odesc[size_t(i)].dims;
-        if (rows > 0 && !dims.empty()) dims[0] = rows;
-        const int cap = outputs[i].shape.dims ? outputs[i].shape.num_dims : 0;
-        const int nd = int(dims.size());
-        if (outputs[i].shape.dims) {
-            const int nw = nd < cap ? nd : cap;
-            for (int j = 0; j < nw; ++j) outputs[i].shape.dims[j] = dims[size_t(j)];
-            outputs[i].shape.num_dims = nw;
-        }
-    }
-}
-
-// Device-side accounting behind ModelGetMetadata.description: what ran (planner FLOPs / bytes) and how long the device took.
-void ModelObj::Account(ie::DeviceModel& d, const ie::PlanInstance& pi) {
-    const double ms = d.last_forward_ms();
-    if (ms <= 0) return;
-    std::lock_guard<std::mutex> g(acct_mu);
-    acct_ms += ms;
-    acct_flops += pi.plan.total_flops;
-    acct_bytes += pi.plan.total_bytes;
-    acct_forwards += 1;
-    acct_images += pi.plan.inputs.empty() || pi.plan.inputs[0].dims.empty() ? 0 : pi.plan.inputs[0].dims[0];
-}
-
-// Run one device batch described by gather/scatter segments over `rows` rows (rows == 0: the shapes are used as they are and the
-// batch cannot be cut).  One lane, or -- allow_shard, num_shards > 1 and at least one row per replica -- contiguous row slices on
-// all shard lanes at once (slice k on worker thread k-1, slice 0 on the calling thread).  Returns a COPY of the output descriptors
-// of the plan that ran, taken while the lane is still held: once a lane is released any other request may take it and `Prepare` a
-// new shape there, which can evict (free) this plan instance from the lane's bounded cache.
-std::vector<ie::IoDesc> ModelObj::RunOnLanes(const std::vector<std::vector<int64_t>>& shapes, int64_t rows, bool allow_shard, const Segs& segs,
-                                             bool* sharded) {
-    const int S = num_shards;
-    *sharded = false;
-    if (!(allow_shard && S > 1 && rows >= S)) {
-        const int k = pool.AcquireAny();
-        if (k < 0) throw std::runtime_error("Model not loaded");
-        try {
-            ie::DeviceModel& D = *lanes[size_t(k)];
-            ie::PlanInstance& pi = D.Prepare(shapes, false);
-            D.InferHostSegments(pi, segs.first, segs.second);
-            Account(D, pi);
-            std::vector<ie::IoDesc> outs = pi.plan.outputs;
-            pool.Release(k, 1);
-            return outs;
-        } catch (...) {
-            pool.Release(k, 1);
-            throw;
-        }
-    }
-    pool.AcquireRange(S);
-    std::vector<std::string> errs(static_cast<size_t>(S));
-    std::vector<ie::PlanInstance*> pis(static_cast<size_t>(S), nullptr);
-    auto run_slice = [&](int k) {
-        try {
-            ie::DeviceModel& D = *lanes[size_t(k)];
-            const int64_t r0 = rows * k / S, r1 = rows * (k + 1) / S, nr = r1 - r0;
-            std::vector<std::vector<int64_t>> sh = shapes;
-            for (auto& x : sh) x[0] = nr;
-            ie::PlanInstance& pi = D.Prepare(sh, false);
-            pis[size_t(k)] = &pi;
-            Segs mine;
-            mine.first.resize(segs.first.size());
-            mine.second.resize(segs.second.size());
-            for (size_t i = 0; i < segs.first.size() && i < pi.plan.inputs.size(); ++i) {
-                if (segs.first[i].empty()) continue;
-                const size_t row_bytes = size_t(pi.plan.inputs[i].view.numel() / nr) * (segs.first[i][0].u8 ? 1 : sizeof(float));
-                const size_t a = size_t(r0) * row_bytes, b = size_t(r1) * row_bytes;
-                for (const auto& sg : segs.first[i]) {
-                    const size_t lo = std::max(sg.dev_off, a), hi = std::min(sg.dev_off + sg.need, b);
-                    if (hi <= lo) continue;
-                    const size_t delta = lo - sg.dev_off;
-                    ie::DeviceModel::InSeg n2{sg.host ? static_cast<const char*>(sg.host) + delta : nullptr,
-                                              sg.have > delta ? std::min(sg.have - delta, hi - lo) : 0, hi - lo, lo - a, sg.u8};
-                    mine.first[i].push_back(n2);
-                }
-            }
-            for (size_t j = 0; j < segs.second.size() && j < pi.plan.outputs.size(); ++j) {
-                const size_t row_bytes = size_t(pi.plan.outputs[j].view.numel() / nr) * sizeof(float);
-                const size_t a = size_t(r0) * row_bytes, b = size_t(r1) * row_bytes;
-                for (const auto& sg : segs.second[j]) {
-                    const size_t nb = std::min(sg.cap, sg.need);
-                    const size_t lo = std::max(sg.dev_off, a), hi = std::min(sg.dev_off + nb, b);
-                    if (hi <= lo) continue;
-                    mine.second[j].push_back({static_cast<char*>(sg.host) + (lo - sg.dev_off), hi - lo, hi - lo, lo - a});
-                }
-            }
-            D.InferHostSegments(pi, mine.first, mine.second);
-            Account(D, pi);
-        } catch (const std::exception& e) {
-            errs[size_t(k)] = e.what();
-        } catch (...) {
-            errs[size_t(k)] = "unknown error";
-        }
-    };
-    for (int k = 1; k < S; ++k) workers.Submit(size_t(k - 1), [&run_slice, k] { run_slice(k); });
-    run_slice(0);
-    workers.Wait();
-    std::vector<ie::IoDesc> outs0;
-    if (pis[0]) outs0 = pis[0]->plan.outputs;
-    pool.Release(0, S);
-    for (auto& e : errs) if (!e.empty()) throw std::runtime_error(e);
-    // the slices wrote only the bytes they produced: zero-fill whatever a caller buffer has beyond its result
-    for (const auto& outs : segs.second)
-        for (const auto& sg : outs) {
-            const size_t nb = std::min(sg.cap, sg.need);
-            if (sg.cap > nb) std::memset(static_cast<char*>(sg.host) + nb, 0, sg.cap - nb);
-        }
-    *sharded = true;
-    return outs0;
-}
-
-void ModelObj::Execute(std::vector<Pending*>& batch) {
-    std::shared_lock<std::shared_mutex> g(life);
-    auto fail_all = [&](const std::string& msg) { for (auto* r : batch) { r->ok = false; r->err = msg; } };
-    if (!loaded.load() || lanes.empty()) { fail_all("Model not loaded"); return; }
-    try {
-        const bool coalesced = !(batch.size() == 1 && !(batchable && max_batch > 1 && batch[0]->rows > 0));
-        const size_t nin = info.inputs.size(), nout = info.outputs.size();
-        Segs segs;
-        segs.first.resize(nin);
-        segs.second.resize(nout);
-        // elements per row of every graph input / output come from the request's own shapes (inputs) and the model (outputs are
-        // sized by the plan: the segment's `need` is clipped by InferHostSegments against the planned tensor)
-        auto row_elems = [](const std::vector<int64_t>& sh) { size_t n = 1; for (size_t k = 1; k < sh.size(); ++k) n *= size_t(sh[k]); return n; };
-        if (!coalesced) {
-            Pending& r = *batch[0];
-            const int64_t rows = r.shapes.empty() || r.shapes[0].empty() ? 0 : r.shapes[0][0];
-            bool same_rows = rows > 0 && batchable;
-            for (auto& sh : r.shapes) if (sh.empty() || sh[0] != rows) same_rows = false;
-            bool sharded = false;
-            if (same_rows && num_shards > 1 && rows >= num_shards) {
-                // per-row sizes need the output row size: take it from the primary's plan for one row per shard ... the plan for the
-                // slice is only known inside the slice, so describe outputs by the model's declared dims instead
-                for (size_t i = 0; i < nin; ++i) {
-                    const size_t rb = row_elems(r.shapes[i]) * (r.in_u8[i] ? 1 : sizeof(float));
-                    segs.first[i].push_back({r.in_ptr[i], r.in_ptr[i] ? r.in_bytes[i] : 0, size_t(rows) * rb, 0, r.in_u8[i] != 0});
-                }
-                for (int j = 0; j < r.num_outputs && size_t(j) < nout; ++j) {
-                    const TensorData& o = r.outputs[j];
-                    if (o.data_type != DATATYPE_FLOAT32 || !o.data || o.data_size == 0) continue;
-                    size_t re = 1;
-                    bool known = !info.outputs[size_t(j)].dims.empty();
-                    for (size_t k = 1; k < info.outputs[size_t(j)].dims.size(); ++k) {
-                        if (info.outputs[size_t(j)].dims[k] <= 0) known = false;
-                        else re *= size_t(info.outputs[size_t(j)].dims[k]);
-                    }
-                    if (!known) { same_rows = false; break; }
-                    segs.second[size_t(j)].push_back({o.data, o.data_size, size_t(rows) * re * sizeof(float), 0});
-                }
-            }
-            if (same_rows && num_shards > 1 && rows >= num_shards) {
-                const std::vector<ie::IoDesc> outs = RunOnLanes(r.shapes, rows, true, segs, &sharded);
-                write_out_dims(r.outputs, r.num_outputs, outs, rows);
-                if (sharded) shard_calls.fetch_add(1);
-                r.ok = true;
-                return;
-            }
-            // ---- one request on one lane ----
-            const int k = pool.AcquireAny();
-            if (k < 0) { fail_all("Model not loaded"); return; }
-            try {
-                ie::DeviceModel& D = *lanes[size_t(k)];
-                ie::PlanInstance& pi = D.Prepare(r.shapes, false);
-                std::vector<void*> out_ptr;
-                std::vector<size_t> out_bytes;
-                for (int i = 0; i < r.num_outputs; ++i) {
-                    const bool copy = r.outputs[i].data_type == DATATYPE_FLOAT32 && r.outputs[i].data && r.outputs[i].data_size > 0;
-                    out_ptr.push_back(copy ? r.outputs[i].data : nullptr);
-                    out_bytes.push_back(copy ? r.outputs[i].data_size : 0);
-                }
-                D.InferHost(pi, r.in_ptr, r.in_bytes, out_ptr, out_bytes, r.in_u8);
-                Account(D, pi);
-                write_out_dims(r.outputs, r.num_outputs, pi.plan.outputs, 0);
-                pool.Release(k, 1);
-            } catch (...) {
-                pool.Release(k, 1);
-                throw;
-            }
-            r.ok = true;
-            return;
-        }
-        // ---- coalesced batch: rows of all callers back to back, padded up to a power-of-two bucket so only a handful of
-        //      plans / hipGraphs ever exist; with shard replicas the bucket is cut over them like a single large request ----
-        int64_t total = 0;
-        for (auto* r : batch) total += r->rows;
-        int64_t bucket = 1;
-        while (bucket < total) bucket <<= 1;
-        if (bucket > max_batch && total <= max_batch) bucket = max_batch;
-        std::vector<std::vector<int64_t>> shapes = batch[0]->shapes;
-        for (auto& sh : shapes) sh[0] = bucket;
-        std::vector<size_t> out_row_bytes(nout, 0);
-        bool out_known = true;
-        for (size_t j = 0; j < nout; ++j) {
-            size_t re = 1;
-            if (info.outputs[j].dims.empty()) out_known = false;
-            for (size_t k = 1; k < info.outputs[j].dims.size(); ++k) {
-                if (info.outputs[j].dims[k] <= 0) out_known = false;
-                else re *= size_t(info.outputs[j].dims[k]);
-            }
-            out_row_bytes[j] = re * sizeof(float);
-        }
-        if (!out_known) {      // output row size only known from a plan: take it from a one-lane plan of the bucket
-            const int k = pool.AcquireAny();
-            if (k < 0) { fail_all("Model not loaded"); return; }
-            try {
-                ie::PlanInstance& pi = lanes[size_t(k)]->Prepare(shapes, false);
-                for (size_t j = 0; j < nout && j < pi.plan.outputs.size(); ++j) out_row_bytes[j] = size_t(pi.plan.outputs[j].view.numel() / bucket) * sizeof(float);
-                pool.Release(k, 1);
-            } catch (...) { pool.Release(k, 1); throw; }
-        }
-        int64_t row0 = 0;
-        for (auto* r : batch) {
-            for (size_t k = 0; k < nin; ++k) {
-                const size_t rb = row_elems(shapes[k]) * sizeof(float);
-                segs.first[k].push_back({r->in_ptr[k], r->in_bytes[k], size_t(r->rows) * rb, size_t(row0) * rb});
-            }
-            for (int j = 0; j < r->num_outputs && size_t(j) < nout; ++j) {
-                const TensorData& o = r->outputs[j];
-                if (o.data_type != DATATYPE_FLOAT32 || !o.data || o.data_size == 0) continue;
-                segs.second[size_t(j)].push_back({o.data, o.data_size, size_t(r->rows) * out_row_bytes[size_t(j)], size_t(row0) * out_row_bytes[size_t(j)]});
-            }
-            row0 += r->rows;
-        }
-        // rows of the bucket beyond `total` stay whatever the input buffer held: they are padding whose results nobody reads
-        bool sharded = false;
-        const std::vector<ie::IoDesc> outs = RunOnLanes(shapes, bucket, out_known, segs, &sharded);
-        device_batches.fetch_add(1);
-        coalesced_requests.fetch_add(int64_t(batch.size()));
-        if (sharded) shard_calls.fetch_add(1);
-        for (auto* r : batch) {
-            write_out_dims(r->outputs, r->num_outputs, outs, r->rows);
-            r->ok = true;
-        }
-    } catch (const std::exception& e) {
-        fail_all(std::string("ONNX inference error: ") + e.what());
-    }
-}
-
-void ModelObj::RunBatched(Pending& req) {
-    std::unique_lock<std::mutex> lk(bmu);
-    queue.push_back(&req);
-    bcv.notify_all();                                  // a waiting leader re-checks whether its batch is full
-    while (!req.done) {
-        if (leader_active) { bcv.wait(lk); continue; }
-        leader_active = true;                          // this caller drives the next device batch
-        const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(batch_window_us);
-        auto queued_rows = [&] { int64_t n = 0; for (auto* r : queue) n += r->rows; return n; };
-        while (queued_rows() < max_batch && bcv.wait_until(lk, deadline) != std::cv_status::timeout) {}
-        std::vector<Pending*> batch;
-        int64_t rows = 0;
-        for (auto it = queue.begin(); it != queue.end();) {
-            Pending* r = *it;
-            bool compatible = batch.empty();
-            if (!compatible) {
-                compatible = rows + r->rows <= max_batch;
-                for (size_t k = 0; k < r->shapes.size() && compatible; ++k)
-                    compatible = std::equal(r->shapes[k].begin() + 1, r->shapes[k].end(), batch[0]->shapes[k].begin() + 1,
-                                            batch[0]->shapes[k].end());
-            }
-            if (compatible) { batch.push_back(r); rows += r->rows; it = queue.erase(it); }
-            else ++it;
-        }
-        lk.unlock();
-        Execute(batch);
-        lk.lock();
-        for (auto* r : batch) r->done = true;
-        leader_active = false;
-        bcv.notify_all();
-    }
-}
-
-}  // namespace
-
 
 namespace {
 // Runtime facts of a loaded model.  json == false: one line of key=value pairs for ModelMetadata.description; json == true: the
