@@ -99,6 +99,32 @@ int main() {
                         tc[3] * 1e3, (t2 - t0) * 1e3);
             std::free(fresh);
         }
+        // (a4) the same FRESH pageable buffer uploaded by several threads at once, each its own slice on its own stream
+        for (int nt : {1, 2, 3, 4}) {
+            std::vector<hipStream_t> sts(nt);
+            for (auto& s2 : sts) CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+            double best = 1e9;
+            for (int rep = 0; rep < 4; ++rep) {
+                char* fresh = static_cast<char*>(std::malloc(n));
+                std::memset(fresh, rep, n);
+                const size_t per = (n / nt + 4095) & ~size_t(4095);
+                double t0 = now();
+                std::vector<std::thread> th;
+                for (int i = 0; i < nt; ++i)
+                    th.emplace_back([&, i] {
+                        const size_t b = std::min(n, per * i), e = std::min(n, per * (i + 1));
+                        if (e > b) {
+                            (void)hipMemcpyAsync(static_cast<char*>(dev) + b, fresh + b, e - b, hipMemcpyHostToDevice, sts[i]);
+                            (void)hipStreamSynchronize(sts[i]);
+                        }
+                    });
+                for (auto& t : th) t.join();
+                best = std::min(best, now() - t0);
+                std::free(fresh);
+            }
+            std::printf("%zu MB FRESH pageable, %d threads x own stream: %.3f ms (%.1f GB/s)\n", mb, nt, best * 1e3, n / best / 1e9);
+            for (auto& s2 : sts) (void)hipStreamDestroy(s2);
+        }
         // (e) D2H small: 128 KB pinned
         for (int rep = 0; rep < 3; ++rep) {
             double t0 = now();

@@ -1629,6 +1629,27 @@ def test_fp8_resnet_mini_every_tile(tmp_path, tile):
     assert e_emu < F8_EMU_RTOL and e_ref < F8_RTOL
 
 
+@pytest.mark.parametrize("image", [64, 50])
+def test_fp8_stem_and_max_pool_one_launch_or_two(tmp_path, image):
+    """fp8 mode: the stem conv + max pool as one launch (only the pooled tensor is quantised, conv_stem_kernel<POOL>) and as two (IE_NO_STEM_POOL=1:
+    the stem's e4m3 output is pooled by pool_f8_kernel) -- each against the emulation of ITS plan (oracle/fp8.py knows both), both inside the fp8
+    bound of the float64 oracle; even and odd conv sizes."""
+    from oracle import fp8 as F
+    mb = models.resnet(3, layers=(2, 1), width=16, image=image, classes=20, seed=59)
+    path = models.write_repo(str(tmp_path), "resnet_f8sp", mb)
+    x = models.synthetic_input((3, 3, image, image), stream="resnet_f8sp")
+    ref = O.run(O.load_model(mb), {"data": x}, dtype=np.float64)["logits"]
+    errs = []
+    for env in ({}, dict(IE_NO_STEM_POOL="1")):
+        y, info = _fp8_run(path, "resnet_f8sp", x, "data", "logits", [3, 20], dict(IE_AUTOTUNE="0", **env))
+        plan, blob = _run_with_env(dict(IE_PRECISION="fp8", **env), lambda: (B.DescribeModel(path, 3)["plan"], B.PlanWeights(path, 3)))
+        assert (plan["steps"][0]["algo"] == "stem") == bool(env) and (plan["steps"][0]["algo"] == "stem_pool") == (not env)
+        emu = F.run_plan(plan, blob, {"data": x}, act_scales=info["f8_act_scales"], fp8=True)["logits"]
+        errs.append((rel_err(y, emu), rel_err(y, ref)))
+        assert errs[-1][0] < F8_EMU_RTOL and errs[-1][1] < F8_RTOL_MINI
+    print(f"fp8 stem + pool image {image}: one launch vs emulation {errs[0][0]:.2e} / float64 {errs[0][1]:.2e}; two launches {errs[1][0]:.2e} / {errs[1][1]:.2e}")
+
+
 @pytest.mark.parametrize("tile", [100, 101, 102, 103, 104, 200, 201, 202, 203])
 def test_fp8_weights_stationary_kernels(tmp_path, tile):
     """conv1x1_ws_f8_kernel (tiles 100-104, also its DUAL form for the projection shortcut of the first block and its STRIDED-input form for the
