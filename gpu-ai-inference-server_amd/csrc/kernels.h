@@ -111,7 +111,7 @@ bool ConvWs32Eligible(const ConvArgs& a, int tile);
 hipError_t LaunchConvWs1x1F32(const ConvArgs& a, int tile, hipStream_t stream);
 hipError_t InitKernelsWs32();
 // fp16 weights-stationary 3x3/s1/p1 conv (Cout <= 32, all weights of the layer resident in LDS, raster window per 64-channel slice)
-constexpr int kNumConvWs3Tiles = 4;
+constexpr int kNumConvWs3Tiles = 5;
 bool ConvWs3Eligible(const ConvArgs& a, int tile);
 hipError_t LaunchConvWs3x3F16(const ConvArgs& a, int tile, hipStream_t stream);
 hipError_t InitKernelsWs3();

@@ -541,7 +541,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_ws_f16_kernel(const ConvAr
 }
 
 struct Ws3Tile { int waves, tmw, pit; };
-constexpr Ws3Tile kWs3Tiles[kNumConvWs3Tiles] = {{4, 2, 12}, {4, 1, 8}, {8, 1, 6}, {2, 1, 12}};
+constexpr Ws3Tile kWs3Tiles[kNumConvWs3Tiles] = {{4, 2, 12}, {4, 1, 8}, {8, 1, 6}, {2, 1, 12}, {12, 1, 6}};      // {12, 1, 6}: three waves per SIMD beside the 83 KB of resident weights (384-pixel tiles: the window still fits)
 
 static size_t ws3_lds_bytes(int tile, int Cin, int PW) {
     const Ws3Tile t = kWs3Tiles[tile];
@@ -615,6 +615,7 @@ hipError_t LaunchConvWs3x3F16(const ConvArgs& a_in, int tile, hipStream_t stream
         case 1: return launch_ws3_t<1>(a, stream);
         case 2: return launch_ws3_t<2>(a, stream);
         case 3: return launch_ws3_t<3>(a, stream);
+        case 4: return launch_ws3_t<4>(a, stream);
         default: return hipErrorInvalidValue;
     }
 }
@@ -624,7 +625,7 @@ hipError_t InitKernelsWs3() {
 #define IE_WS3(T)                                                                                                             \
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_ws_f16_kernel<kWs3Tiles[T].waves, kWs3Tiles[T].tmw, kWs3Tiles[T].pit>), \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-    IE_WS3(0) IE_WS3(1) IE_WS3(2) IE_WS3(3)
+    IE_WS3(0) IE_WS3(1) IE_WS3(2) IE_WS3(3) IE_WS3(4)
 #undef IE_WS3
     return hipSuccess;
 }

@@ -960,9 +960,9 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                                       (32 * (s.in.c + 4) + 2 * s.in.c + 32 + (t == 12 ? 4 : 2) * 32 * 36) * 4 <= 160 * 1024)) &&
                            !(ws_tn[t] > 1 && N <= 32 * (ws_tn[t] / 2)) && N % 4 == 0 && s.out.pitch % 4 == 0 && s.out.c_off % 4 == 0;
                 };
-                static const int ws3_cfg[4][3] = {{4, 2, 12}, {4, 1, 8}, {8, 1, 6}, {2, 1, 12}};   // waves, row blocks per wave, prefetch depth
+                static const int ws3_cfg[5][3] = {{4, 2, 12}, {4, 1, 8}, {8, 1, 6}, {2, 1, 12}, {12, 1, 6}};   // waves, row blocks per wave, prefetch depth (kWs3Tiles, kernels_ws.hip)
                 auto ws3_ok = [&](int t3) {
-                    if (t3 < 0 || t3 >= 4) return false;
+                    if (t3 < 0 || t3 >= 5) return false;
                     const int64_t pr3 = 32 * ws3_cfg[t3][1] * ws3_cfg[t3][0] + 2 * (s.in.w + 1) + 2;
                     return vec16_ok && s.out.f16 && is3x3 && !n.has_pre && N % 8 == 0 && s.out.pitch % 8 == 0 && s.out.c_off % 8 == 0 &&
                            pr3 <= ws3_cfg[t3][2] * (64 * ws3_cfg[t3][0] / 8) && (9 * ((s.in.c + 63) / 64) * 32 + pr3) * 144 + 128 <= 160 * 1024;
@@ -1035,7 +1035,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                         int t = 0;
                         if (const char* ft = env.get("IE_FORCE_TILE")) { int v = std::atoi(ft); if (v >= 0 && v < (in16 ? 12 : 14)) t = v; }
                         if (ws16_ok(t) || ws32_ok(t)) { s.algo = ConvAlgo::Ws1x1; s.tile = t; }
-                        else if (ws3_ok(t % 4)) { s.algo = ConvAlgo::Ws3x3; s.tile = t % 4; }
+                        else if (ws3_ok(t % 5)) { s.algo = ConvAlgo::Ws3x3; s.tile = t % 5; }
                         else if (s.algo == ConvAlgo::Naive && vec16_ok) s.algo = ConvAlgo::IgemmVec;
                     }
                     else if (f == "direct") {

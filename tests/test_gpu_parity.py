@@ -1000,7 +1000,7 @@ def test_unknown_precision_is_a_load_error(model_repo):
 # classifier.  The reference holds no ResNet file or output, so this family is "parity unpinned" by the reference as well: the
 # checker is the float64 oracle on the same synthetic graph.
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("tile", range(4))
+@pytest.mark.parametrize("tile", range(5))
 def test_fp16_weights_stationary_3x3_wide_outputs(tmp_path, tile):
     """conv3x3_ws_f16_kernel with more than 32 output channels (one resident weight set per 32-channel N-tile, blockIdx.y): the
     64->64 and 128->128 3x3 convs of a ResNet, every tile variant."""
