@@ -856,7 +856,7 @@ void DeviceModel::Autotune(PlanInstance& pi, size_t nsteps, bool allow_search) {
                             best[t] = std::min(best[t], ms);
                         }
                     }
-                    choice = best[1] <= best[0] ? 1 : 0;
+                    choice = best[1] <= best[0] * 1.05f ? 1 : 0;      // within the timer's noise the single launch wins: it moves a third of the bytes
                     if (env_.get("IE_TUNE_LOG")) std::fprintf(stderr, "[tune] stem + pool %s: one launch %.1f us, two launches %.1f us\n", s.name.c_str(), best[1] * 1e3, best[0] * 1e3);
                     std::lock_guard<std::mutex> g(w_->tune_mu);
                     w_->tune_cache[keys] = {choice, 1};
