@@ -326,6 +326,9 @@ static hipError_t launch_ws8_t(const ConvArgs& a, hipStream_t stream) {
     int per_cu = int((size_t(160) * 1024) / lds);
     per_cu = per_cu < 1 ? 1 : (per_cu > 2048 / (64 * WAVES) ? 2048 / (64 * WAVES) : per_cu);
     if (per_cu > 2) per_cu = 2;                      // (the grid that measured best; see launch_ws_t in kernels_ws.hip on sizing by true residency)
+#ifdef WS8_PER_CU
+    per_cu = WS8_PER_CU;                             // (probe builds)
+#endif
     const int gy = (a.out.c + 32 * TN - 1) / (32 * TN);
     int slots = cus * per_cu / gy;
     if (slots < 8) slots = 8;

@@ -1,7 +1,9 @@
 // Standalone timing of conv1x1_ws_f16_kernel (kernels_ws.hip) on a dense-block-1 shaped layer, with parts switched off at compile time:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I gpu-ai-inference-server_amd/csrc [-DWS_ABLATE=n] scripts/probes/ws_probe.cpp -o build/ws_probe_n
 //   build/ws_probe_n <K> <tile>
-// WS_ABLATE: 0 whole kernel, 1 no weight preamble, 2 no BN+ReLU prologue, 3 no stores, 4 no MFMA / LDS fragment reads, 5 no activation loads.
+// WS_ABLATE: 0 whole kernel, 1 no weight preamble, 2 no BN+ReLU prologue, 3 no stores (out-of-range offsets: dropped by the hardware), 5 no activation
+// loads (out-of-range offsets: zeros, at once), 8 neither loads nor stores = the on-chip work alone.  (Skipping the MFMAs instead is not a valid variant:
+// the compiler then removes the loads that fed them.)  -DWS_PER_CU=n overrides the workgroups per CU the persistent grid is sized for.
 #include "../../gpu-ai-inference-server_amd/csrc/kernels_ws.hip"
 
 #include <cstdio>
