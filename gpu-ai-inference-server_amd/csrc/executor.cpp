@@ -94,7 +94,7 @@ namespace {
 
 std::string tune_file_header() {
     std::ostringstream o;
-    o << kTuneFileTag << ' ' << kNumIgemmTiles << ' ' << kNumConvRasterTiles << ' ' << kNumConvWs32Tiles << ' ' << kNumConvWs3Tiles << ' '
+    o << kTuneFileTag << ' ' << kNumIgemmTiles << ' ' << kNumConvRasterTiles << ' ' << kNumConvWs32Tiles << ' ' << kNumConvWs16Tiles << ' ' << kNumConvWs3Tiles << ' '
       << kNumConvDirectTiles << ' ' << kNumConvWinoTiles << ' ' << kNumConvX6Tiles << ' ' << kNumConvWs8Tiles << ' ' << kNumConvWs38Tiles;
     return o.str();
 }
@@ -117,7 +117,8 @@ void load_tune_file(const std::string& path, std::map<std::vector<int64_t>, std:
             key.push_back(v);
         }
         int t = -1, sp = 0;
-        if (ok && (is >> t >> sp) && ((t >= 0 && t < kNumIgemmTiles) || (t >= 100 && t < 100 + kNumConvRasterTiles) || (t >= 200 && t < 200 + kNumConvWs32Tiles) ||
+        if (ok && (is >> t >> sp) && ((t >= 0 && t < kNumIgemmTiles) || (t >= 100 && t < 100 + (kNumConvRasterTiles > kNumConvWs8Tiles ? kNumConvRasterTiles : kNumConvWs8Tiles)) ||      // (fp32: raster tiles; fp8 files: conv1x1_ws_f8 tiles)
+                                        (t >= 200 && t < 200 + (kNumConvWs16Tiles > kNumConvWs32Tiles ? kNumConvWs16Tiles : kNumConvWs32Tiles)) ||
                                        (t >= 300 && t < 300 + kNumConvWs3Tiles) || (t >= 400 && t < 400 + kNumConvDirectTiles) || (t >= 500 && t < 500 + kNumConvWinoTiles) || (t >= 600 && t < 600 + kNumConvX6Tiles)) &&
             sp >= 1 && sp <= 64 && key.size() >= 6)          // (the fused steps have short signatures: stem + pool 7 numbers, dense block 10, dual 9)
             cache[key] = {t, sp};
@@ -1202,7 +1203,7 @@ void DeviceModel::Autotune(PlanInstance& pi, size_t nsteps, bool allow_search) {
             // 1x1/s1: weights-stationary streaming kernel (either precision)
             if (s.algo == ConvAlgo::IgemmVec && s.kh == 1 && s.kw == 1) {
                 ConvArgs probe = MakeConvArgs(pi, s);
-                for (int t = 0; t < (s.in.f16 ? kNumConvWsTiles : kNumConvWs32Tiles); ++t) {
+                for (int t = 0; t < (s.in.f16 ? kNumConvWs16Tiles : kNumConvWs32Tiles); ++t) {
                     if (!(s.in.f16 ? ConvWsEligible(probe, t) : ConvWs32Eligible(probe, t))) continue;
                     Step trial = s;
                     trial.algo = ConvAlgo::Ws1x1;

@@ -99,8 +99,11 @@ hipError_t LaunchConvIgemmF16(const ConvArgs& a, int tile, int splitk, hipStream
 hipError_t InitKernelsF16();
 // fp16 weights-stationary 1x1 conv (kernels_ws.hip): weights in LDS once per persistent workgroup, activations streamed
 // from HBM straight into MFMA fragments.  tile % 6 = {output channels per workgroup, waves}; tile / 6 = 0: persistent workgroups
-// with an even number of row blocks per wave, 1: one row block per wave (the hardware's workgroup dispatch balances the load).
+// with an even number of row blocks per wave, 1: one row block per wave (the hardware's workgroup dispatch balances the load),
+// 2 (fp16 only, tiles 12-17): ONE persistent workgroup per CU -- fewer, longer streams: 10-15 % faster than the fuller grid on DenseNet's
+// block-1 / block-2 shapes at batch 128 (scripts/probes/ws_probe.cpp -DWS_PER_CU), the search decides per shape.
 constexpr int kNumConvWsTiles = 12;
+constexpr int kNumConvWs16Tiles = 18;
 bool ConvWsEligible(const ConvArgs& a, int tile);
 hipError_t LaunchConvWs1x1F16(const ConvArgs& a, int tile, hipStream_t stream);
 hipError_t InitKernelsWs();
@@ -193,7 +196,7 @@ hipError_t LaunchConvIgemmF8(const ConvArgs& a, int tile, hipStream_t stream);
 hipError_t InitKernelsF8();
 // fp8 weights-stationary 1x1 conv (kernels_ws8.hip): weights + epilogue constants in LDS, activations streamed from HBM into MFMA fragments;
 // with a.in2 set also the projection shortcut's GEMM in the same launch.  tile: {N tiles of 32 per workgroup, waves} = {8,8} {4,8} {2,8} {4,4} {2,4}
-constexpr int kNumConvWs8Tiles = 5;
+constexpr int kNumConvWs8Tiles = 10;       // 5 tile shapes x {grid sized for two workgroups per CU, for one (tiles 5-9)}
 bool ConvWs8Eligible(const ConvArgs& a, int tile);
 hipError_t LaunchConvWs1x1F8(const ConvArgs& a, int tile, hipStream_t stream);
 hipError_t InitKernelsWs8();

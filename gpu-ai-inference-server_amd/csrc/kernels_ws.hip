@@ -265,7 +265,7 @@ constexpr WsTile kWsTiles[6] = {{4, 8}, {4, 4}, {2, 8}, {2, 4}, {1, 8}, {1, 4}};
 static size_t ws_lds_bytes(int tn, int K) { return size_t(32 * tn * (K + 8) + 2 * K) * sizeof(_Float16) + size_t(32 * tn) * sizeof(float); }
 
 bool ConvWsEligible(const ConvArgs& a, int tile) {
-    if (tile < 0 || tile >= kNumConvWsTiles) return false;
+    if (tile < 0 || tile >= kNumConvWs16Tiles) return false;
     if (!a.in.f16 || a.w16 == nullptr || a.kh != 1 || a.kw != 1 || a.sh != 1 || a.sw != 1 || a.pt != 0 || a.pl != 0) return false;
     if (a.in.sc != 1 || a.out.sc != 1 || a.in.h != a.out.h || a.in.w != a.out.w) return false;
     if ((a.in.c & 31) || (a.in.sw & 7) || (reinterpret_cast<uintptr_t>(a.in.p) & 15) || (reinterpret_cast<uintptr_t>(a.w16) & 15)) return false;
@@ -290,7 +290,8 @@ bool ConvWsEligible(const ConvArgs& a, int tile) {
 }
 
 template <int TN, int WAVES, bool PRE, bool FAST>
-static hipError_t launch_ws_t(const ConvArgs& a, bool one_per_wave, hipStream_t stream) {
+static hipError_t launch_ws_t(const ConvArgs& a, int grid_variant, hipStream_t stream) {      // 0: LDS / wave-slot heuristic, 1: one row block per wave, 2: one workgroup per CU
+    const bool one_per_wave = grid_variant == 1;
     const int64_t M = int64_t(a.in.n) * a.in.h * a.in.w;
     const int nrb = int((M + 31) / 32);
     const size_t lds = ws_lds_bytes(TN, a.in.c);
@@ -307,6 +308,7 @@ static hipError_t launch_ws_t(const ConvArgs& a, bool one_per_wave, hipStream_t 
     int per_cu = int((size_t(160) * 1024) / lds);
     per_cu = per_cu < 1 ? 1 : (per_cu > 2048 / (64 * WAVES) ? 2048 / (64 * WAVES) : per_cu);
     if (per_cu > 4) per_cu = 4;
+    if (grid_variant == 2) per_cu = 1;
 #ifdef WS_PER_CU
     per_cu = WS_PER_CU;                      // (probe builds)
 #endif
@@ -327,8 +329,8 @@ hipError_t LaunchConvWs1x1F16(const ConvArgs& a_in, int tile, hipStream_t stream
     const bool fast = a.out.f16 && a.res.p == nullptr;
 #define IE_WS(T, TN, W)                                                                                                                                  \
     case T:                                                                                                                                              \
-        return a.pre_scale ? (fast ? launch_ws_t<TN, W, true, true>(a, tile >= 6, stream) : launch_ws_t<TN, W, true, false>(a, tile >= 6, stream))       \
-                           : (fast ? launch_ws_t<TN, W, false, true>(a, tile >= 6, stream) : launch_ws_t<TN, W, false, false>(a, tile >= 6, stream));
+        return a.pre_scale ? (fast ? launch_ws_t<TN, W, true, true>(a, tile / 6, stream) : launch_ws_t<TN, W, true, false>(a, tile / 6, stream))       \
+                           : (fast ? launch_ws_t<TN, W, false, true>(a, tile / 6, stream) : launch_ws_t<TN, W, false, false>(a, tile / 6, stream));
     switch (tile % 6) {
         IE_WS(0, 4, 8) IE_WS(1, 4, 4) IE_WS(2, 2, 8) IE_WS(3, 2, 4) IE_WS(4, 1, 8) IE_WS(5, 1, 4)
         default: return hipErrorInvalidValue;

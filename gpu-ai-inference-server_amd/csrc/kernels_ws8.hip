@@ -262,7 +262,8 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_ws_f8_kernel(const ConvArg
 }
 
 struct Ws8Tile { int tn, waves; };
-constexpr Ws8Tile kWs8Tiles[kNumConvWs8Tiles] = {{8, 8}, {4, 8}, {2, 8}, {4, 4}, {2, 4}};
+constexpr int kNumWs8Shapes = 5;             // tile % 5 = shape; tile / 5 = 1: the persistent grid sized for ONE workgroup per CU
+constexpr Ws8Tile kWs8Tiles[kNumWs8Shapes] = {{8, 8}, {4, 8}, {2, 8}, {4, 4}, {2, 4}};
 
 static size_t ws8_lds_bytes(int tn, int K1, int K2) {
     const size_t bn = size_t(32) * tn;
@@ -297,7 +298,7 @@ bool ConvWs8Eligible(const ConvArgs& a, int tile) {
         const int64_t span2 = int64_t(a.in2.n - 1) * a.in2.sn + int64_t(a.in2.h - 1) * a.in2.sh + int64_t(a.in2.w - 1) * a.in2.sw + a.in2.c;
         if (span2 >= (int64_t(1) << 31) || int64_t(a.out.c) * a.in2.c >= (int64_t(1) << 31)) return false;
     }
-    const Ws8Tile t = kWs8Tiles[tile];
+    const Ws8Tile t = kWs8Tiles[tile % kNumWs8Shapes];
     if (dual && t.tn > 4) return false;                                                       // two accumulator sets: 2 x 4 x 16 registers
     if (ws8_lds_bytes(t.tn, a.in.c, dual ? a.in2.c : 0) > size_t(160) * 1024) return false;
     if (t.tn > 1 && a.out.c <= 32 * (t.tn / 2)) return false;                                 // do not waste MFMA rows on padding
@@ -312,7 +313,7 @@ static void magic_div8(unsigned d, unsigned long long* m, int* sh) {      // flo
 }
 
 template <int TN, int WAVES, bool DUAL, bool STR = false>
-static hipError_t launch_ws8_t(const ConvArgs& a, hipStream_t stream) {
+static hipError_t launch_ws8_t(const ConvArgs& a, bool one_per_cu, hipStream_t stream) {
     const int64_t M = int64_t(a.out.n) * a.out.h * a.out.w;
     const int nrb = int((M + 31) / 32);
     const size_t lds = ws8_lds_bytes(TN, a.in.c, DUAL ? a.in2.c : 0);
@@ -326,6 +327,7 @@ static hipError_t launch_ws8_t(const ConvArgs& a, hipStream_t stream) {
     int per_cu = int((size_t(160) * 1024) / lds);
     per_cu = per_cu < 1 ? 1 : (per_cu > 2048 / (64 * WAVES) ? 2048 / (64 * WAVES) : per_cu);
     if (per_cu > 2) per_cu = 2;                      // (the grid that measured best; see launch_ws_t in kernels_ws.hip on sizing by true residency)
+    if (one_per_cu) per_cu = 1;                      // tiles 5-9: fewer, longer streams (scripts/probes/ws8_probe.cpp -DWS8_PER_CU); the search decides per shape
 #ifdef WS8_PER_CU
     per_cu = WS8_PER_CU;                             // (probe builds)
 #endif
@@ -349,23 +351,25 @@ hipError_t LaunchConvWs1x1F8(const ConvArgs& a_in, int tile, hipStream_t stream)
     ConvArgs a = a_in;
     a.in_bytes = int64_t(a.in.n - 1) * a.in.sn + int64_t(a.in.h - 1) * a.in.sh + int64_t(a.in.w - 1) * a.in.sw + a.in.c;
     const bool dual = a.in2.p != nullptr;
+    const bool pc1 = tile >= kNumWs8Shapes;
+    tile %= kNumWs8Shapes;
     if (dual) a.in2_bytes = int64_t(a.in2.n - 1) * a.in2.sn + int64_t(a.in2.h - 1) * a.in2.sh + int64_t(a.in2.w - 1) * a.in2.sw + a.in2.c;
     if (a.sh != 1 || a.sw != 1) {
         switch (tile) {
-            case 0: return launch_ws8_t<8, 8, false, true>(a, stream);
-            case 1: return launch_ws8_t<4, 8, false, true>(a, stream);
-            case 2: return launch_ws8_t<2, 8, false, true>(a, stream);
-            case 3: return launch_ws8_t<4, 4, false, true>(a, stream);
-            case 4: return launch_ws8_t<2, 4, false, true>(a, stream);
+            case 0: return launch_ws8_t<8, 8, false, true>(a, pc1, stream);
+            case 1: return launch_ws8_t<4, 8, false, true>(a, pc1, stream);
+            case 2: return launch_ws8_t<2, 8, false, true>(a, pc1, stream);
+            case 3: return launch_ws8_t<4, 4, false, true>(a, pc1, stream);
+            case 4: return launch_ws8_t<2, 4, false, true>(a, pc1, stream);
             default: return hipErrorInvalidValue;
         }
     }
     switch (tile) {
-        case 0: return launch_ws8_t<8, 8, false>(a, stream);
-        case 1: return dual ? launch_ws8_t<4, 8, true>(a, stream) : launch_ws8_t<4, 8, false>(a, stream);
-        case 2: return dual ? launch_ws8_t<2, 8, true>(a, stream) : launch_ws8_t<2, 8, false>(a, stream);
-        case 3: return dual ? launch_ws8_t<4, 4, true>(a, stream) : launch_ws8_t<4, 4, false>(a, stream);
-        case 4: return dual ? launch_ws8_t<2, 4, true>(a, stream) : launch_ws8_t<2, 4, false>(a, stream);
+        case 0: return launch_ws8_t<8, 8, false>(a, pc1, stream);
+        case 1: return dual ? launch_ws8_t<4, 8, true>(a, pc1, stream) : launch_ws8_t<4, 8, false>(a, pc1, stream);
+        case 2: return dual ? launch_ws8_t<2, 8, true>(a, pc1, stream) : launch_ws8_t<2, 8, false>(a, pc1, stream);
+        case 3: return dual ? launch_ws8_t<4, 4, true>(a, pc1, stream) : launch_ws8_t<4, 4, false>(a, pc1, stream);
+        case 4: return dual ? launch_ws8_t<2, 4, true>(a, pc1, stream) : launch_ws8_t<2, 4, false>(a, pc1, stream);
         default: return hipErrorInvalidValue;
     }
 }

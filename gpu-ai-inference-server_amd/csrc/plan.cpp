@@ -949,8 +949,10 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                 const bool is3x3 = n.kh == 3 && n.kw == 3 && n.sh == 1 && n.sw == 1 && n.pt == 1 && n.pl == 1 && n.pb == 1 && n.pr == 1;
                 static const int ws_tn[14] = {4, 4, 2, 2, 1, 1, 4, 4, 2, 2, 1, 1, 1, 1};      // 12, 13: fp32 K-split variants (8 / 4 waves)
                 auto ws16_ok = [&](int t) {
-                    return t >= 0 && t < 12 && vec16_ok && is1x1 && s.in.c % 32 == 0 &&
-                           (32 * ws_tn[t] * (s.in.c + 8) + 2 * s.in.c) * 2 + 128 * ws_tn[t] <= 160 * 1024 && !(ws_tn[t] > 1 && N <= 32 * (ws_tn[t] / 2)) &&
+                    if (t < 0 || t >= 18) return false;          // (12-17: the one-workgroup-per-CU grids of shapes 0-5)
+                    const int tn = ws_tn[t % 6];
+                    return vec16_ok && is1x1 && s.in.c % 32 == 0 &&
+                           (32 * tn * (s.in.c + 8) + 2 * s.in.c) * 2 + 128 * tn <= 160 * 1024 && !(tn > 1 && N <= 32 * (tn / 2)) &&
                            (s.out.f16 ? (N % 8 == 0 && s.out.pitch % 8 == 0 && s.out.c_off % 8 == 0) : (N % 4 == 0 && s.out.pitch % 4 == 0 && s.out.c_off % 4 == 0));
                 };
                 auto ws32_ok = [&](int t) {
@@ -1000,7 +1002,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                         if (t >= 0 && t < kNumIgemmBaseTiles && !(kIgemmTiles[t].bn > 32 && N <= 32)) s.tile = t;
                         // >= 100: the weights-stationary 1x1 kernel's tiles, >= 200: the 3x3's (kernels_ws8.hip); a launcher that declines the
                         // operands hands the step back to the tiled kernel (executor)
-                        if (t >= 100 && t < 105 && n.kh == 1 && n.kw == 1) s.tile = t;           // (strided 1x1 convs too: the kernel's STR form)
+                        if (t >= 100 && t < 110 && n.kh == 1 && n.kw == 1) s.tile = t;           // (strided 1x1 convs too: the kernel's STR form)
                         if (t >= 200 && t < 204 && is3x3) s.tile = t;
                     }
                     break;
@@ -1033,7 +1035,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                         s.algo = (vec_ok || vec16_ok) ? ConvAlgo::IgemmVec : (K <= 2048 && !in16 ? ConvAlgo::IgemmScalar : ConvAlgo::Naive);
                     else if (f == "ws") {
                         int t = 0;
-                        if (const char* ft = env.get("IE_FORCE_TILE")) { int v = std::atoi(ft); if (v >= 0 && v < (in16 ? 12 : 14)) t = v; }
+                        if (const char* ft = env.get("IE_FORCE_TILE")) { int v = std::atoi(ft); if (v >= 0 && v < (in16 ? 18 : 14)) t = v; }
                         if (ws16_ok(t) || ws32_ok(t)) { s.algo = ConvAlgo::Ws1x1; s.tile = t; }
                         else if (ws3_ok(t % 5)) { s.algo = ConvAlgo::Ws3x3; s.tile = t % 5; }
                         else if (s.algo == ConvAlgo::Naive && vec16_ok) s.algo = ConvAlgo::IgemmVec;

@@ -1,6 +1,6 @@
 // Standalone timing of conv1x1_ws_f16_kernel (kernels_ws.hip) on a dense-block-1 shaped layer, with parts switched off at compile time:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I gpu-ai-inference-server_amd/csrc [-DWS_ABLATE=n] scripts/probes/ws_probe.cpp -o build/ws_probe_n
-//   build/ws_probe_n <K> <tile>
+//   build/ws_probe_n <K> <tile> [batch = 128] [H = W = 56]
 // WS_ABLATE: 0 whole kernel, 1 no weight preamble, 2 no BN+ReLU prologue, 3 no stores (out-of-range offsets: dropped by the hardware), 5 no activation
 // loads (out-of-range offsets: zeros, at once), 8 neither loads nor stores = the on-chip work alone.  (Skipping the MFMAs instead is not a valid variant:
 // the compiler then removes the loads that fed them.)  -DWS_PER_CU=n overrides the workgroups per CU the persistent grid is sized for.
@@ -22,7 +22,7 @@ int ResidentPerCu(const void* kernel, int block, size_t lds) {
 
 int main(int argc, char** argv) {
     const int K = argc > 1 ? atoi(argv[1]) : 128, tile = argc > 2 ? atoi(argv[2]) : 1, N = 128;
-    const int B = 128, H = 56, W = 56, P = 256;                 // the block buffer's pixel pitch
+    const int B = argc > 3 ? atoi(argv[3]) : 128, H = argc > 4 ? atoi(argv[4]) : 56, W = H, P = K > 256 ? 512 : 256;      // P: the block buffer's pixel pitch
     const size_t npix = size_t(B) * H * W;
     _Float16 *x, *y, *w16, *ps, *pt;
     float* bias;
@@ -46,6 +46,6 @@ int main(int argc, char** argv) {
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
     const double bytes = double(npix) * (K + N) * 2;
-    printf("ablate %d  K=%d tile %d: %.1f us per launch, %.2f TB/s of algorithmic bytes\n", WS_ABLATE, K, tile, ms * 50.f, bytes / (ms / 20 * 1e-3) / 1e12);
+    printf("ablate %d  K=%d tile %d B=%d %dx%d: %.1f us per launch, %.2f TB/s of algorithmic bytes\n", WS_ABLATE, K, tile, B, H, W, ms * 50.f, bytes / (ms / 20 * 1e-3) / 1e12);
     return 0;
 }

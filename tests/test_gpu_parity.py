@@ -806,11 +806,12 @@ def test_fp16_every_tile_and_split_k(tmp_path, tile, splitk):
     assert e < F16_RTOL, (tile, splitk, e)
 
 
-@pytest.mark.parametrize("tile", range(12))
+@pytest.mark.parametrize("tile", range(18))
 @pytest.mark.parametrize("image", [40, 112])
 def test_fp16_weights_stationary_kernels(tmp_path, tile, image):
     """conv1x1_ws_f16_kernel (weights in LDS once per persistent workgroup, activations streamed into MFMA fragments) and
-    conv3x3_ws_f16_kernel (all weights of the layer resident in LDS, raster window per 64-channel slice): every tile variant,
+    conv3x3_ws_f16_kernel (all weights of the layer resident in LDS, raster window per 64-channel slice): every tile variant (1x1: six shapes x three
+    grid policies -- persistent, one row block per wave, one workgroup per CU),
     single-tile and multi-tile persistent loops (image 112 -> 28x28 and 14x14 feature maps, several raster tiles per workgroup)."""
     mb = models.densenet(3, growth=32, blocks=(2, 2), stem=32, image=image, classes=40, seed=78)
     path = models.write_repo(str(tmp_path), "f16ws", mb)
@@ -1650,9 +1651,9 @@ def test_fp8_stem_and_max_pool_one_launch_or_two(tmp_path, image):
     print(f"fp8 stem + pool image {image}: one launch vs emulation {errs[0][0]:.2e} / float64 {errs[0][1]:.2e}; two launches {errs[1][0]:.2e} / {errs[1][1]:.2e}")
 
 
-@pytest.mark.parametrize("tile", [100, 101, 102, 103, 104, 200, 201, 202, 203])
+@pytest.mark.parametrize("tile", [100, 101, 102, 103, 104, 105, 107, 109, 200, 201, 202, 203])
 def test_fp8_weights_stationary_kernels(tmp_path, tile):
-    """conv1x1_ws_f8_kernel (tiles 100-104, also its DUAL form for the projection shortcut of the first block and its STRIDED-input form for the
+    """conv1x1_ws_f8_kernel (tiles 100-104; 105-109: the same shapes on a grid of one workgroup per CU; also its DUAL form for the projection shortcut of the first block and its STRIDED-input form for the
     stride-2 projection shortcut of the second stage) and conv3x3_ws_f8_kernel (tiles
     200-203) forced on a bottleneck ResNet whose channel counts are multiples of 32 (every 1x1 / 3x3 stride-1 conv qualifies): against the fp8
     plan emulation (same quantisation points: kernel correctness), the float64 oracle (stated fp8 bound) and the tiled fp8 kernel's answer."""
