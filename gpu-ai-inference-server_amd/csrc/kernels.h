@@ -201,7 +201,7 @@ bool ConvWs8Eligible(const ConvArgs& a, int tile);
 hipError_t LaunchConvWs1x1F8(const ConvArgs& a, int tile, hipStream_t stream);
 hipError_t InitKernelsWs8();
 // fp8 weights-stationary 3x3/s1/p1 conv (kernels_ws8.hip): all weights of a 32-channel N tile resident in LDS, raster window per 128-channel slice
-constexpr int kNumConvWs38Tiles = 4;
+constexpr int kNumConvWs38Tiles = 8;      // 4 tile shapes x {grid sized by LDS (<= two workgroups per CU), one workgroup per CU (tiles 4-7)}
 bool ConvWs38Eligible(const ConvArgs& a, int tile);
 hipError_t LaunchConvWs3x3F8(const ConvArgs& a, int tile, hipStream_t stream);
 // w8[o, :] = e4m3(w[o, :] / wscale[o]) with wscale[o] = max|w[o, :]| / 448, one workgroup per row

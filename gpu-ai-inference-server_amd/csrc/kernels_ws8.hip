@@ -554,7 +554,8 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_ws_f8_kernel(const ConvArg
 }
 
 struct Ws3Tile8 { int waves, tmw, pit; };
-constexpr Ws3Tile8 kWs3Tiles8[kNumConvWs38Tiles] = {{4, 2, 12}, {4, 1, 8}, {8, 1, 6}, {8, 2, 10}};
+constexpr int kNumWs38Shapes = 4;
+constexpr Ws3Tile8 kWs3Tiles8[kNumWs38Shapes] = {{4, 2, 12}, {4, 1, 8}, {8, 1, 6}, {8, 2, 10}};
 
 static size_t ws38_lds_bytes(int tile, int Cin, int PW) {
     const Ws3Tile8 t = kWs3Tiles8[tile];
@@ -572,14 +573,14 @@ bool ConvWs38Eligible(const ConvArgs& a, int tile) {
     if (a.out.sh != a.out.sw * a.out.w || a.out.sn != a.out.sh * a.out.h) return false;
     const int64_t Mr = int64_t(a.in.n) * (a.in.h + 1) * (a.in.w + 1), Mpix = int64_t(a.in.n) * a.in.h * a.in.w;
     if (Mr + 4096 >= (int64_t(1) << 31) || Mpix * a.in.sw >= (int64_t(1) << 31) || Mpix * a.out.sw >= (int64_t(1) << 31) || int64_t(a.out.c) * 9 * a.in.c >= (int64_t(1) << 31)) return false;
-    const Ws3Tile8 t = kWs3Tiles8[tile];
+    const Ws3Tile8 t = kWs3Tiles8[tile % kNumWs38Shapes];
     const int PR = 32 * t.tmw * t.waves + 2 * (a.in.w + 1) + 2;
     if (PR > t.pit * (64 * t.waves / 8)) return false;
-    return ws38_lds_bytes(tile, a.in.c, a.in.w + 1) <= size_t(160) * 1024;
+    return ws38_lds_bytes(tile % kNumWs38Shapes, a.in.c, a.in.w + 1) <= size_t(160) * 1024;
 }
 
 template <int T, int NKK>
-static hipError_t launch_ws38_t(const ConvArgs& a, hipStream_t stream) {
+static hipError_t launch_ws38_t(const ConvArgs& a, bool one_per_cu, hipStream_t stream) {
     constexpr Ws3Tile8 t = kWs3Tiles8[T];
     constexpr int BMp = 32 * t.tmw * t.waves;
     Ws3Geom8 g;
@@ -601,6 +602,7 @@ static hipError_t launch_ws38_t(const ConvArgs& a, hipStream_t stream) {
     }
     int per_cu = int((size_t(160) * 1024) / lds);
     per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
+    if (one_per_cu) per_cu = 1;                      // tiles 4-7
     const int gy = (a.out.c + 31) / 32;
     int slots = cus * per_cu / gy;
     if (slots < 1) slots = 1;
@@ -615,8 +617,9 @@ hipError_t LaunchConvWs3x3F8(const ConvArgs& a_in, int tile, hipStream_t stream)
     ConvArgs a = a_in;
     a.in_bytes = int64_t(a.in.n - 1) * a.in.sn + int64_t(a.in.h - 1) * a.in.sh + int64_t(a.in.w - 1) * a.in.sw + a.in.c;
     const bool half_slice = a.in.c <= 64;             // a 64-channel layer fills half of the 128-channel slice: two fragment pairs per tap instead of four
-#define IE_WS38(T) case T: return half_slice ? launch_ws38_t<T, 2>(a, stream) : launch_ws38_t<T, 4>(a, stream);
-    switch (tile) {
+#define IE_WS38(T) case T: return half_slice ? launch_ws38_t<T, 2>(a, pc1, stream) : launch_ws38_t<T, 4>(a, pc1, stream);
+    const bool pc1 = tile >= kNumWs38Shapes;
+    switch (tile % kNumWs38Shapes) {
         IE_WS38(0) IE_WS38(1) IE_WS38(2) IE_WS38(3)
         default: return hipErrorInvalidValue;
     }

@@ -1003,7 +1003,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                         // >= 100: the weights-stationary 1x1 kernel's tiles, >= 200: the 3x3's (kernels_ws8.hip); a launcher that declines the
                         // operands hands the step back to the tiled kernel (executor)
                         if (t >= 100 && t < 110 && n.kh == 1 && n.kw == 1) s.tile = t;           // (strided 1x1 convs too: the kernel's STR form)
-                        if (t >= 200 && t < 204 && is3x3) s.tile = t;
+                        if (t >= 200 && t < 208 && is3x3) s.tile = t;
                     }
                     break;
                 }

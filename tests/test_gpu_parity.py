@@ -1651,11 +1651,11 @@ def test_fp8_stem_and_max_pool_one_launch_or_two(tmp_path, image):
     print(f"fp8 stem + pool image {image}: one launch vs emulation {errs[0][0]:.2e} / float64 {errs[0][1]:.2e}; two launches {errs[1][0]:.2e} / {errs[1][1]:.2e}")
 
 
-@pytest.mark.parametrize("tile", [100, 101, 102, 103, 104, 105, 107, 109, 200, 201, 202, 203])
+@pytest.mark.parametrize("tile", [100, 101, 102, 103, 104, 105, 107, 109, 200, 201, 202, 203, 204, 206])
 def test_fp8_weights_stationary_kernels(tmp_path, tile):
     """conv1x1_ws_f8_kernel (tiles 100-104; 105-109: the same shapes on a grid of one workgroup per CU; also its DUAL form for the projection shortcut of the first block and its STRIDED-input form for the
     stride-2 projection shortcut of the second stage) and conv3x3_ws_f8_kernel (tiles
-    200-203) forced on a bottleneck ResNet whose channel counts are multiples of 32 (every 1x1 / 3x3 stride-1 conv qualifies): against the fp8
+    200-203; 204-207: one workgroup per CU) forced on a bottleneck ResNet whose channel counts are multiples of 32 (every 1x1 / 3x3 stride-1 conv qualifies): against the fp8
     plan emulation (same quantisation points: kernel correctness), the float64 oracle (stated fp8 bound) and the tiled fp8 kernel's answer."""
     from oracle import fp8 as F
     mb = models.resnet(3, layers=(2, 2), width=32, image=64, classes=20, seed=53)
