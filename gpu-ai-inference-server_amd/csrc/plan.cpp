@@ -1327,12 +1327,18 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
             if (pl.out.f16 != c.out.f16 || pl.out.f8 != c.out.f8 || pl.out.nchw || pl.out.buf == c.out.buf || pl.out.buf == c.in.buf) continue;
             if (pl.out.h != (c.out.h + 2 - 3) / 2 + 1 || pl.out.w != (c.out.w + 2 - 3) / 2 + 1) continue;
             if (pl.out.pitch % 8 || pl.out.c_off % 8 || (pl.out.f8 && (pl.out.pitch % 16 || pl.out.c_off % 16))) continue;
-            bool ok = true;                       // the conv's output must have no other reader
-            for (size_t q = i + 2; q < plan.steps.size() && ok; ++q) {
+            // the conv's output must have no other reader: walk the launches behind the pool in execution order (a fused step = its parts) until the
+            // buffer is written again -- recycled for another tensor, so the stem's tensor was dead by then (liveness pass)
+            bool ok = true, recycled = false;
+            auto visit = [&](const Step& u) {
+                if (recycled || !ok) return;
+                if (u.in.buf == c.out.buf || (u.has_in2 && u.in2.buf == c.out.buf)) ok = false;
+                else if (u.out.buf == c.out.buf) recycled = true;
+            };
+            for (size_t q = i + 2; q < plan.steps.size() && ok && !recycled; ++q) {
                 const Step& t = plan.steps[q];
-                if (t.in.buf == c.out.buf || (t.has_in2 && t.in2.buf == c.out.buf)) ok = false;
-                for (const Step& tp : t.parts) if (tp.in.buf == c.out.buf || (tp.has_in2 && tp.in2.buf == c.out.buf)) ok = false;
-                if (t.out.buf == c.out.buf) break;             // recycled for another tensor: dead by then
+                if (t.parts.empty()) visit(t);
+                else for (const Step& tp : t.parts) visit(tp);
             }
             for (size_t o = 0; o < out_vals.size() && ok; ++o) if (view_of(out_vals[o]).buf == c.out.buf) ok = false;
             if (!ok) continue;

@@ -1558,6 +1558,29 @@ def test_requests_never_wait_for_a_kernel_search(tmp_path):
         m2.Destroy()
 
 
+def test_fused_step_choices_survive_a_restart(tmp_path):
+    """The fused steps' timed choices (fp16: dense-block chain vs its plain launches, stem + pool as one launch or two) have short signatures in the tune
+    file; a second model of the same directory must find them there and search nothing (the file is not rewritten)."""
+    mb = models.densenet("N", growth=32, blocks=(2, 3), stem=64, image=56, classes=10, seed=13)
+    path = models.write_repo(str(tmp_path), "tuned16", mb, config_json='{"tune_batches": [4], "precision": "fp16"}')
+    cache = os.path.join(path, ".ie_tune.fp16.txt")
+    m = B.CreateModel(path, "tuned16")
+    try:
+        assert os.path.exists(cache)
+        stamp = (os.stat(cache).st_mtime_ns, open(cache).read())
+        keys = [ln.split(":")[0].split() for ln in stamp[1].splitlines()[1:]]
+        assert any(len(k) == 7 for k in keys) and any(len(k) == 10 for k in keys), sorted({len(k) for k in keys})     # stem + pool, dense block
+        plan = _run_with_env(dict(IE_PRECISION="fp16"), lambda: B.DescribeModel(path, 4)["plan"])
+        assert plan["steps"][0]["algo"] == "stem_pool" and any(s.get("algo") == "dense_block" for s in plan["steps"])
+    finally:
+        m.Destroy()
+    m2 = B.CreateModel(path, "tuned16")
+    try:
+        assert (os.stat(cache).st_mtime_ns, open(cache).read()) == stamp
+    finally:
+        m2.Destroy()
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # fp8 precision mode (BASELINE.json configs[4]: ResNet-50 fp8).  The reference never computes in fp8: parity unpinned.
 # Checkers: (1) the OFP8 E4M3 format restated in numpy (oracle/fp8.py) against the device conversion, code for code;
