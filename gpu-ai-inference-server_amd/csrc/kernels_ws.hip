@@ -80,7 +80,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_ws_f16_kernel(const ConvAr
         // U loads in flight per thread: a one-at-a-time loop would pay the L2 round trip BN*K/(8*NT) times in a row
         constexpr int U = 8;
         const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(w), 0, Cout * K * 2, 0x00020000);
-        for (int idx0 = tid; idx0 < (WS_ABLATE == 1 ? 0 : BN * k8); idx0 += U * NT) {
+        auto stage_trip = [&](int idx0) {
             u32x4 v[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -95,7 +95,12 @@ __global__ __launch_bounds__(64 * WAVES) void conv1x1_ws_f16_kernel(const ConvAr
                 const int row = idx / k8, ck = idx - row * k8;
                 if (idx < BN * k8) *reinterpret_cast<u32x4*>(sB + row * P + ck * 8) = v[u];
             }
-        }
+        };
+        // The first trip is peeled: behind a loop header the compiler drains every load in flight (s_waitcnt vmcnt(0)) -- the ring requested above
+        // would complete before the first weight load is even issued, and the two HBM / L2 latencies would add up instead of overlapping.
+        const int wtotal = WS_ABLATE == 1 ? 0 : BN * k8;
+        if (tid < wtotal) stage_trip(tid);
+        for (int idx0 = tid + U * NT; idx0 < wtotal; idx0 += U * NT) stage_trip(idx0);
         for (int idx = tid; idx < BN; idx += NT) sBias[idx] = (a.bias != nullptr && n0 + idx < Cout) ? a.bias[n0 + idx] : 0.f;
         if constexpr (PRE) {
             const _Float16* const ps = static_cast<const _Float16*>(a.pre_scale16);
