@@ -108,8 +108,9 @@ bool ConvWsEligible(const ConvArgs& a, int tile);
 hipError_t LaunchConvWs1x1F16(const ConvArgs& a, int tile, hipStream_t stream);
 hipError_t InitKernelsWs();
 // fp32 twin (kernels_ws32.hip): same tile table, v_mfma_f32_32x32x2_f32, float in / float out; two more tiles (12, 13) are the
-// K-split variants (8 / 4 waves of a workgroup share one row block and split K, partial tiles summed through LDS)
-constexpr int kNumConvWs32Tiles = kNumConvWsTiles + 2;
+// K-split variants (8 / 4 waves of a workgroup share one row block and split K, partial tiles summed through LDS); 14-19: shapes 0-5 on a grid
+// of ONE persistent workgroup per CU (as the fp16 tiles 12-17)
+constexpr int kNumConvWs32Tiles = kNumConvWsTiles + 2 + 6;
 bool ConvWs32Eligible(const ConvArgs& a, int tile);
 hipError_t LaunchConvWs1x1F32(const ConvArgs& a, int tile, hipStream_t stream);
 hipError_t InitKernelsWs32();

@@ -377,11 +377,11 @@ bool ConvWs32Eligible(const ConvArgs& a, int tile) {
         if (a.res.f16 || a.res.sc != 1 || (a.res.sw % 4) || (reinterpret_cast<uintptr_t>(a.res.p) % 16)) return false;
         if (a.res.sh != a.res.w * a.res.sw || a.res.sn != a.res.h * a.res.sh || M * a.res.sw * 4 >= (int64_t(1) << 31)) return false;
     }
-    if (tile >= kNumConvWsTiles) {                     // K-split variants: every wave needs at least one 16-channel chunk
+    if (tile >= kNumConvWsTiles && tile < kNumConvWsTiles + 2) {      // K-split variants: every wave needs at least one 16-channel chunk
         const int waves = tile == kNumConvWsTiles ? 8 : 4;
         return a.in.c / 16 >= waves && wsk32_lds_bytes(waves, a.in.c) <= size_t(160) * 1024;
     }
-    const Ws32Tile t = kWs32Tiles[tile % 6];
+    const Ws32Tile t = kWs32Tiles[(tile >= kNumConvWsTiles + 2 ? tile - (kNumConvWsTiles + 2) : tile) % 6];
     if (ws32_lds_bytes(t.tn, a.in.c) > size_t(160) * 1024) return false;
     if (t.tn > 1 && a.out.c <= 32 * (t.tn / 2)) return false;                               // do not waste MFMA rows on padding
     return true;
@@ -413,7 +413,8 @@ static hipError_t launch_wsk32_t(const ConvArgs& a, hipStream_t stream) {
 }
 
 template <int TN, int WAVES, bool PRE>
-static hipError_t launch_ws32_t(const ConvArgs& a, bool one_per_wave, hipStream_t stream) {
+static hipError_t launch_ws32_t(const ConvArgs& a, int grid_variant, hipStream_t stream) {      // 0: LDS / wave-slot heuristic, 1: one row block per wave, 2: one workgroup per CU
+    const bool one_per_wave = grid_variant == 1;
     const int64_t M = int64_t(a.in.n) * a.in.h * a.in.w;
     const int nrb = int((M + 31) / 32);
     const size_t lds = ws32_lds_bytes(TN, a.in.c);
@@ -430,6 +431,7 @@ static hipError_t launch_ws32_t(const ConvArgs& a, bool one_per_wave, hipStream_
     int per_cu = int((size_t(160) * 1024) / lds);
     per_cu = per_cu < 1 ? 1 : (per_cu > 2048 / (64 * WAVES) ? 2048 / (64 * WAVES) : per_cu);
     if (per_cu > 4) per_cu = 4;
+    if (grid_variant == 2) per_cu = 1;
     int slots = cus * per_cu / gy;
     if (slots < 8) slots = 8;
     const int iters = one_per_wave ? 1 : (nrb + slots * WAVES - 1) / (slots * WAVES);
@@ -447,9 +449,11 @@ hipError_t LaunchConvWs1x1F32(const ConvArgs& a_in, int tile, hipStream_t stream
     a.in_bytes = 4 * (int64_t(a.in.n - 1) * a.in.sn + int64_t(a.in.h - 1) * a.in.sh + int64_t(a.in.w - 1) * a.in.sw + int64_t(a.in.c - 1) + 1);
     if (tile == kNumConvWsTiles) return a.pre_scale ? launch_wsk32_t<8, true>(a, stream) : launch_wsk32_t<8, false>(a, stream);
     if (tile == kNumConvWsTiles + 1) return a.pre_scale ? launch_wsk32_t<4, true>(a, stream) : launch_wsk32_t<4, false>(a, stream);
+    const bool pc1 = tile >= kNumConvWsTiles + 2;                     // 14-19: shapes 0-5, one workgroup per CU
+    const int shape = (pc1 ? tile - (kNumConvWsTiles + 2) : tile) % 6, variant = pc1 ? 2 : (tile >= 6 ? 1 : 0);
 #define IE_WS(T, TN, W) \
-    case T: return a.pre_scale ? launch_ws32_t<TN, W, true>(a, tile >= 6, stream) : launch_ws32_t<TN, W, false>(a, tile >= 6, stream);
-    switch (tile % 6) {
+    case T: return a.pre_scale ? launch_ws32_t<TN, W, true>(a, variant, stream) : launch_ws32_t<TN, W, false>(a, variant, stream);
+    switch (shape) {
         IE_WS(0, 4, 8) IE_WS(1, 4, 4) IE_WS(2, 2, 8) IE_WS(3, 2, 4) IE_WS(4, 1, 8) IE_WS(5, 1, 4)
         default: return hipErrorInvalidValue;
     }

@@ -956,6 +956,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                            (s.out.f16 ? (N % 8 == 0 && s.out.pitch % 8 == 0 && s.out.c_off % 8 == 0) : (N % 4 == 0 && s.out.pitch % 4 == 0 && s.out.c_off % 4 == 0));
                 };
                 auto ws32_ok = [&](int t) {
+                    if (t >= 14 && t < 20) t -= 14;              // 14-19: shapes 0-5 on a grid of one workgroup per CU: same operand conditions
                     return t >= 0 && t < 14 && vec_ok && !s.out.f16 && is1x1 && s.in.c % 16 == 0 &&
                            (t < 12 ? (32 * ws_tn[t] * (s.in.c + 4) + 2 * s.in.c + 32 * ws_tn[t]) * 4 <= 160 * 1024
                                    : (s.in.c / 16 >= (t == 12 ? 8 : 4) &&
@@ -1035,7 +1036,7 @@ Plan BuildPlan(const OnnxModel& m, const std::vector<std::vector<int64_t>>& inpu
                         s.algo = (vec_ok || vec16_ok) ? ConvAlgo::IgemmVec : (K <= 2048 && !in16 ? ConvAlgo::IgemmScalar : ConvAlgo::Naive);
                     else if (f == "ws") {
                         int t = 0;
-                        if (const char* ft = env.get("IE_FORCE_TILE")) { int v = std::atoi(ft); if (v >= 0 && v < (in16 ? 18 : 14)) t = v; }
+                        if (const char* ft = env.get("IE_FORCE_TILE")) { int v = std::atoi(ft); if (v >= 0 && v < (in16 ? 18 : 20)) t = v; }
                         if (ws16_ok(t) || ws32_ok(t)) { s.algo = ConvAlgo::Ws1x1; s.tile = t; }
                         else if (ws3_ok(t % 5)) { s.algo = ConvAlgo::Ws3x3; s.tile = t % 5; }
                         else if (s.algo == ConvAlgo::Naive && vec16_ok) s.algo = ConvAlgo::IgemmVec;

@@ -511,10 +511,11 @@ def test_dynamic_batcher_coalesces_concurrent_requests(densenet_repo):
         m.Destroy()
 
 
-@pytest.mark.parametrize("tile", range(14))
+@pytest.mark.parametrize("tile", range(20))
 def test_fp32_weights_stationary_1x1_kernel(tmp_path, tile):
     """conv1x1_ws_f32_kernel (weight slice resident in LDS, persistent workgroups, activations streamed from HBM straight into
-    MFMA fragments through a register ring): every {channels per workgroup, waves} variant, multi-round persistent loops."""
+    MFMA fragments through a register ring): every {channels per workgroup, waves} variant, multi-round persistent loops (14-19: the six shapes on
+    a grid of one workgroup per CU)."""
     mb = models.densenet(3, growth=32, blocks=(2, 2), stem=128, image=112, classes=40, seed=78)     # K = 96 .. 192
     path = models.write_repo(str(tmp_path), "f32ws", mb)
     om = O.load_model(mb)
